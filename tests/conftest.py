@@ -1,0 +1,56 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this process")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden_meta():
+    with open(os.path.join(GOLDEN, "meta.json")) as fh:
+        return json.load(fh)
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False))
+
+
+def cfg_of(case):
+    from oracle.restate import Cfg
+    return Cfg(embed_dim=case["E"], num_heads=case["H"], num_layers=case["L"], max_seq_length=case["max_seq"],
+               max_nmr_length=case["max_nmr"], max_memory_length=case["max_mem"], use_stablemax=case["sm"])
+
+
+def case_inputs(case, seed=0):
+    from oracle import fill
+    ir = fill.synth_ir(case["B"], 1000, seed)
+    nmr = fill.synth_tokens(case["B"], case["N"], 0, 1000, seed)
+    tgt = fill.synth_tokens(case["B"], case["T"] + 1, 15, 591, seed + 1)
+    tgt[:, 0] = 12
+    return ir, nmr, tgt
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

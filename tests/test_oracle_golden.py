@@ -1,0 +1,121 @@
+"""Pins oracle/restate.py against the golden vectors that oracle/gen_golden.py produced from the
+reference's own ``models`` package (CPU only; no GPU, no /root/reference needed)."""
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, case_inputs, cfg_of, load_golden, rel_err
+from oracle import fill, restate
+from oracle.shapes import formula_state_dict, state_shapes
+
+TOL = 2e-5   # same ATen kernels, same weights, same inputs: only threading/blocking differences
+
+
+@pytest.mark.parametrize("name", ["tiny_sm", "d100_sm", "d128_sdpa", "d192_sm", "d512_sm", "test_config"])
+def test_forward_matches_reference(golden_meta, name):
+    case = golden_meta["cases"][name]
+    cfg = cfg_of(case)
+    sd = formula_state_dict(cfg)
+    ir, nmr, tgt = case_inputs(case)
+    g = load_golden(name)
+    taps = {}
+    with torch.no_grad():
+        logits = restate.model_forward(sd, cfg, nmr, ir, tgt[:, :-1], taps=taps)
+    assert rel_err(taps["memory"][:2], g["memory"]) < TOL
+    assert rel_err(logits, g["logits"]) < TOL
+    n_taps = 0
+    for k, v in g.items():
+        if k.startswith("tap."):
+            assert rel_err(taps[k[4:]], v) < TOL, k
+            n_taps += 1
+    if name == "tiny_sm":
+        assert n_taps >= 12
+
+
+def test_state_dict_contract():
+    # 297 keys at 8 layers, 289 of them parameters
+    cfg = restate.Cfg(embed_dim=1600, num_heads=16, num_layers=8, max_seq_length=95, max_nmr_length=190,
+                      max_memory_length=32, use_stablemax=True)
+    shp = state_shapes(cfg)
+    assert len(shp) == 297
+    assert sum(1 for k in shp if not k.endswith("inv_freq")) == 289
+    n = sum(int(torch.tensor(s).prod()) for k, s in shp.items() if not k.endswith("inv_freq"))
+    assert n == 318_078_479     # SURVEY.md section 6 (oracle-measured on the reference)
+
+
+@pytest.mark.parametrize("name", ["tiny_sm", "d100_sm", "d128_sdpa"])
+def test_backward_matches_reference(golden_meta, name):
+    case = golden_meta["cases"][name]
+    cfg = cfg_of(case)
+    sd = formula_state_dict(cfg)
+    for k, v in sd.items():
+        if not k.endswith("inv_freq"):
+            v.requires_grad_(True)
+    ir, nmr, tgt = case_inputs(case)
+    ir = ir.clone().requires_grad_(True)
+    g = load_golden(name)
+    loss = restate.train_loss(sd, cfg, nmr, ir, tgt, training=False)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    assert rel_err(ir.grad, g["grad.ir"]) < 1e-4
+    for k, v in g.items():
+        if k.startswith("grad.") and k != "grad.ir":
+            assert rel_err(sd[k[5:]].grad, v) < 1e-4, k
+    with open(os.path.join(GOLDEN, f"{name}.gradsums.json")) as fh:
+        sums = json.load(fh)
+    for k, (s, a) in sums.items():
+        gr = sd[k].grad.double()
+        assert abs(float(gr.abs().sum()) - a) <= 1e-4 * a + 1e-9, k
+
+
+def test_train_mode_droppath_matches_reference(golden_meta):
+    case = golden_meta["cases"]["tiny_sm"]
+    cfg = cfg_of(case)
+    sd = formula_state_dict(cfg)
+    ir, nmr, tgt = case_inputs(case)
+    g = load_golden("tiny_sm")
+    torch.manual_seed(2024)
+    with torch.no_grad():
+        logits = restate.model_forward(sd, cfg, nmr, ir, tgt[:, :-1], training=True)
+    assert rel_err(logits, g["logits_train_seed2024"]) < TOL
+    # and the eval logits differ from it (DropPath really fired)
+    assert rel_err(g["logits"], g["logits_train_seed2024"]) > 1e-4
+
+
+@pytest.mark.parametrize("name", ["tiny_sm", "d100_sm", "d128_sdpa", "test_config"])
+def test_greedy_ids_match_reference(golden_meta, name):
+    case = golden_meta["cases"][name]
+    cfg = cfg_of(case)
+    sd = formula_state_dict(cfg)
+    gold = golden_meta["greedy"][name]
+    ir8 = fill.synth_ir(8, 1000, 5)
+    nmr8 = fill.synth_tokens(8, case["N"], 0, 1000, 5)
+    seqs = restate.greedy_decode_ids(sd, cfg, nmr8, ir8, gold["max_len"])
+    assert seqs == gold["ids"]
+
+
+def test_tokenizer_bit_identical(golden_meta):
+    vocab = restate.read_vocab(os.path.join(GOLDEN, "vocab.txt"))
+    tk = golden_meta["tokenizer"]
+    assert len(vocab) == tk["n_vocab"] == 591
+    for k, v in tk["special"].items():
+        assert vocab[k] == v
+    assert (vocab["[PAD]"], vocab["[UNK]"], vocab["[CLS]"], vocab["[SEP]"]) == (
+        restate.PAD_ID, restate.UNK_ID, restate.BOS_ID, restate.EOS_ID)
+    for s, ids in tk["encodings"].items():
+        assert restate.encode_smiles(s, vocab) == ids, s
+
+
+def test_kv_cache_legality_on_oracle(golden_meta):
+    """logits of a prefix do not depend on later target tokens."""
+    case = golden_meta["cases"]["tiny_sm"]
+    cfg = cfg_of(case)
+    sd = formula_state_dict(cfg)
+    ir, nmr, tgt = case_inputs(case)
+    with torch.no_grad():
+        mem = restate.spectral_encoder(sd, ir, cfg)
+        full = restate.smiles_decoder(sd, tgt[:, :12], mem, nmr, cfg)
+        part = restate.smiles_decoder(sd, tgt[:, :5], mem, nmr, cfg)
+    assert rel_err(part, full[:, :5]) < 1e-5
