@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Per-kernel microbenchmarks (GPU): achieved GB/s or TFLOP/s from algorithmic bytes/flops."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multimodal_amd import ops, _lib as L  # noqa: E402
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def bench_k1(B, C, Ln, dtype, bwd=False):
+    d = torch.device("cuda:0")
+    x = torch.rand(B, Ln, C, device=d).to(dtype)
+    w = torch.randn(C, 1, 7, device=d); b = torch.zeros(C, device=d); lw = torch.ones(C, device=d); lb = torch.zeros(C, device=d)
+    es = x.element_size()
+    if not bwd:
+        t = timeit(lambda: ops.dwconv7_ln_fwd(x, w, b, lw, lb))
+        nbytes = B * C * Ln * 2 * es
+    else:
+        y, mean, rstd = ops.dwconv7_ln_fwd(x, w, b, lw, lb, save_stats=True)
+        dy = torch.randn_like(x)
+        t = timeit(lambda: ops.dwconv7_ln_bwd(x, dy, None, w, b, lw, mean, rstd))
+        nbytes = B * C * Ln * 3 * es
+    return dict(kernel="dwconv7_ln_" + ("bwd" if bwd else "fwd"), B=B, C=C, L=Ln, dtype=str(dtype), us=t * 1e6, GBps=nbytes / t / 1e9)
+
+
+def bench_gemm(M, N, K, dtype, akm=False, bkm=False):
+    d = torch.device("cuda:0")
+    a = (torch.rand((K, M) if akm else (M, K), device=d) * 2 - 1).to(dtype)
+    b = (torch.rand((K, N) if bkm else (N, K), device=d) * 2 - 1).to(dtype)
+    t = timeit(lambda: ops.gemm(a, b, M, N, K, a_kmajor=akm, b_kmajor=bkm))
+    tt = timeit(lambda: torch.matmul(a.t() if akm else a, b if bkm else b.t()))
+    return dict(kernel="gemm", M=M, N=N, K=K, dtype=str(dtype), layout=f"{int(akm)}{int(bkm)}", us=t * 1e6,
+                TFLOPs=2 * M * N * K / t / 1e12, torch_TFLOPs=2 * M * N * K / tt / 1e12)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="k1,gemm")
+    a = ap.parse_args()
+    res = []
+    if "k1" in a.what:
+        for dt in (torch.float32, torch.bfloat16):
+            for (B, C, Ln) in [(8192, 64, 250), (8192, 128, 125), (8192, 256, 62), (4096, 1600, 31), (32, 64, 250), (32, 256, 62), (32, 1600, 31)]:
+                res.append(bench_k1(B, C, Ln, dt)); print(json.dumps(res[-1]), flush=True)
+            for (B, C, Ln) in [(8192, 64, 250), (8192, 256, 62), (2048, 1600, 31), (32, 64, 250)]:
+                res.append(bench_k1(B, C, Ln, dt, bwd=True)); print(json.dumps(res[-1]), flush=True)
+    if "gemm" in a.what:
+        for dt in (torch.bfloat16, torch.float32):
+            for (M, N, K) in [(10080, 6400, 1600), (10080, 1600, 6400), (10080, 1600, 1600), (992, 6400, 1600), (992, 1600, 6400), (8000, 256, 64), (4096, 4096, 4096)]:
+                res.append(bench_gemm(M, N, K, dt)); print(json.dumps(res[-1]), flush=True)
+            res.append(bench_gemm(10080, 1600, 6400, dt, False, True)); print(json.dumps(res[-1]), flush=True)
+            res.append(bench_gemm(6400, 1600, 10080, dt, True, True)); print(json.dumps(res[-1]), flush=True)

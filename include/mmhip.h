@@ -1,0 +1,164 @@
+/* libmmhip -- C ABI of the MI355X (gfx950) hot path of tomoqt/multimodal.
+ *
+ * The reference has no FFI: its hot path is a chain of ATen calls inside nn.Modules
+ * (SURVEY.md 8b).  Each entry point below replaces the ATen op sequence cited next to
+ * it (paths relative to the reference repository).  Conventions:
+ *   - every pointer is a DEVICE pointer unless named host_*; the caller owns all
+ *     buffers, including workspaces; nothing here allocates or frees;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued there, never synced;
+ *   - activations are f32 (MM_F32) or bf16 (MM_BF16) as selected by `dtype`;
+ *     parameters named `const float*` are always f32 master copies;
+ *   - return MM_OK or a negative code; mm_last_error() gives the message
+ *     (thread-local).  Nothing throws across this boundary.
+ */
+#ifndef MMHIP_H
+#define MMHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_OK 0
+#define MM_ERR_ARG (-1)
+#define MM_ERR_LAUNCH (-2)
+#define MM_ERR_UNSUPPORTED (-3)
+
+enum { MM_F32 = 0, MM_BF16 = 1 };
+enum { MM_LAYOUT_BLC = 0, /* channels-last  [B][L][C] */
+       MM_LAYOUT_BCL = 1  /* channel-major  [B][C][L] (nn.Conv1d's layout) */ };
+enum { MM_ATTN_SOFTMAX = 0, MM_ATTN_STABLEMAX = 1 };
+
+int mm_version(void);
+const char* mm_last_error(void);
+
+/* ---- K1: depthwise Conv1d(k=7,pad=3,groups=C) + transpose + LayerNorm(C) ------------------
+ * replaces models/convnext.py:38-40 (self.dwconv; transpose(1,2); self.norm).
+ * x: [B][L][C] (MM_LAYOUT_BLC) or [B][C][L] (MM_LAYOUT_BCL); y: [B][L][C].
+ * w: [C][7] (= dwconv.weight (C,1,7)), b: [C], ln_w/ln_b: [C].
+ * mean/rstd: [B*L] row statistics for the backward pass, may both be NULL. */
+int mm_dwconv7_ln_fwd(const void* x, const float* w, const float* b, const float* ln_w, const float* ln_b,
+                      void* y, float* mean, float* rstd, int64_t B, int64_t C, int64_t L, float eps,
+                      int dtype, int in_layout, void* stream);
+
+/* backward of the above (autograd of models/convnext.py:38-40), channels-last x/dy/dx.
+ * dres (nullable, [B][L][C]) is added into dx (the block's residual gradient, convnext.py:47).
+ * dw:[C][7] db,dln_w,dln_b:[C] are OVERWRITTEN (deterministic two-stage reduction).
+ * workspace: at least mm_dwconv7_ln_bwd_workspace(B,C,L) bytes. */
+size_t mm_dwconv7_ln_bwd_workspace(int64_t B, int64_t C, int64_t L);
+int mm_dwconv7_ln_bwd(const void* x, const void* dy, const void* dres, const float* w, const float* b,
+                      const float* ln_w, const float* mean, const float* rstd, void* dx, float* dw, float* db,
+                      float* dln_w, float* dln_b, void* workspace, size_t workspace_bytes, int64_t B, int64_t C,
+                      int64_t L, int dtype, void* stream);
+
+/* ---- stem: Conv1d(1,C0,k=4,s=4) + LayerNorm(C0), channels-last output ----------------------
+ * replaces models/convnext.py:67-72.  x: f32 [B][Lin]; w: [C0][4]; y: [B][Lo][C0], Lo=(Lin-4)/4+1. */
+int mm_stem_ln_fwd(const float* x, const float* w, const float* b, const float* ln_w, const float* ln_b, void* y,
+                   float* mean, float* rstd, int64_t B, int64_t Lin, int64_t C0, float eps, int dtype, void* stream);
+size_t mm_stem_ln_bwd_workspace(int64_t B, int64_t Lin, int64_t C0);
+int mm_stem_ln_bwd(const float* x, const void* dy, const float* w, const float* b, const float* ln_w,
+                   const float* mean, const float* rstd, float* dx /*nullable [B][Lin]*/, float* dw, float* db,
+                   float* dln_w, float* dln_b, void* workspace, size_t workspace_bytes, int64_t B, int64_t Lin,
+                   int64_t C0, int dtype, void* stream);
+
+/* ---- row LayerNorm over the last dim ------------------------------------------------------
+ * replaces nn.LayerNorm at models/convnext.py:78,:131 and models/transformer_decoder.py:122,:160,:306.
+ * x: [G][Lin][C]; y: [G][Lout][C] with Lout <= Lin: rows l >= Lout of each group are dropped
+ * (that is Conv1d(k=2,s=2) discarding an odd tail, convnext.py:80).  Plain LN: G=1, Lin=Lout=rows. */
+int mm_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                     int64_t G, int64_t Lin, int64_t Lout, int64_t C, float eps, int dtype, void* stream);
+size_t mm_layernorm_bwd_workspace(int64_t rows, int64_t C);
+int mm_layernorm_bwd(const void* x, const void* dy, const void* dres /*nullable, x-shaped, added into dx*/,
+                     const float* w, const float* mean, const float* rstd, void* dx, float* dw, float* db,
+                     void* workspace, size_t workspace_bytes, int64_t G, int64_t Lin, int64_t Lout, int64_t C,
+                     int dtype, void* stream);
+
+/* ---- GEMM family (MFMA; bf16 or exact-f32 matrix cores) -----------------------------------
+ * out[M][N] = epilogue( A[M][K] . B^T ), B given as [N][K] (nn.Linear weight layout).
+ * Replaces F.linear / nn.Linear at models/convnext.py:41,:43,:80,:134 and the matmuls autograd
+ * derives from them.  Operand layouts: *_kmajor = 0 means the reduction index is contiguous
+ * ([rows][K], leading dimension ld*), 1 means it is the slow index ([K][rows]).
+ * Epilogues (applied in f32 on the accumulator, in this order):
+ *   acc += bias[n]                       if bias
+ *   if pre:  pre[m][n] = acc             (saved pre-activation, training)
+ *   act: 0 none | 1 GELU(erf) (convnext.py:42) | 2 relu(x)^2 (transformer_decoder.py:161)
+ *   if mul:  acc *= dact(mul[m][n])      (backward: mul holds the saved pre-activation; act selects
+ *                                         the DERIVATIVE: 1 GELU', 2 2*relu)  [act then means dact]
+ *   if gamma: acc *= gamma[n]            (LayerScale, convnext.py:45)
+ *   if rowscale: acc *= rowscale[m / rows_per_scale]   (DropPath factor, convnext.py:17)
+ *   if res:  acc += res[m][n]            (residual, convnext.py:47)
+ * split_k > 1 needs workspace of split_k*M*N floats and a plain epilogue (bias only). */
+typedef struct {
+    const void* A; const void* B; void* out;
+    int64_t M, N, K;
+    int64_t lda, ldb, ldo;
+    int a_kmajor, b_kmajor;
+    int dtype;            /* dtype of A, B (MM_F32 | MM_BF16) */
+    int out_dtype;        /* dtype of out, pre, res, mul */
+    const float* bias;    /* [N] or NULL */
+    void* pre;            /* [M][N] (ldo) or NULL */
+    const void* mul;      /* [M][N] (ldo) or NULL */
+    int act;
+    const float* gamma;   /* [N] or NULL */
+    const float* rowscale; int64_t rows_per_scale;
+    const void* res;      /* [M][N] (ldo) or NULL */
+    int split_k; void* workspace; size_t workspace_bytes;
+} mm_gemm_args;
+int mm_gemm(const mm_gemm_args* args, void* stream);
+
+/* column sums: out[n] = sum_m x[m][n] (bias gradients); optional gamma/z terms for LayerScale:
+ * replaces the bias-gradient reductions autograd derives from nn.Linear. workspace: see _workspace. */
+size_t mm_colsum_workspace(int64_t M, int64_t N);
+int mm_colsum(const void* x, float* out, void* workspace, size_t workspace_bytes, int64_t M, int64_t N,
+              int64_t ld, int dtype, void* stream);
+
+/* ---- K3: prefix-LM attention with partial RoPE, softmax or stablemax ----------------------
+ * replaces models/transformer_decoder.py:129-153 (+ the mask of :295-298, built in-kernel).
+ * q,k,v: [B][S][H][d] with row stride ld_qkv elements between consecutive s (so a fused [B][S][3E]
+ * projection works); o: [B][S][H][d] contiguous.  Query i may see key j iff j <= i or
+ * (i < prompt_len and j < prompt_len).  RoPE (NeoX half rotation) is applied to the first rot dims
+ * of q and k at absolute position s, from cos/sin tables [S][rot/2] (f32).
+ * lse: [B][H][S] f32 row normaliser saved for backward (softmax: m + log l; stablemax: sum of s),
+ * may be NULL. */
+int mm_prefix_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* cos_t,
+                       const float* sin_t, int64_t B, int64_t H, int64_t S, int64_t d, int64_t rot,
+                       int64_t prompt_len, int64_t ld_qkv, int mode, int dtype, void* stream);
+int mm_prefix_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                       void* dq, void* dk, void* dv, const float* cos_t, const float* sin_t, int64_t B, int64_t H,
+                       int64_t S, int64_t d, int64_t rot, int64_t prompt_len, int64_t ld_qkv, int64_t ld_dqkv,
+                       int mode, int dtype, void* stream);
+
+/* ---- K4: one decode step of attention against a KV cache ----------------------------------
+ * no counterpart in the reference (it recomputes the full decoder every step,
+ * train_autoregressive.py:97-101); equals row `pos` of K3 by the argument of SURVEY.md A9.
+ * q,k_new,v_new: [B][H][d] for the token at absolute position pos (ld_qkv = elements between b rows).
+ * RoPE is applied to q and k_new; k_new (rotated) and v_new are appended at slot pos of
+ * kcache/vcache [B][H][Smax][d]; o: [B][H][d] = attention of q over slots 0..pos. */
+int mm_decode_attn(const void* q, const void* k_new, const void* v_new, void* kcache, void* vcache, void* o,
+                   const float* cos_t, const float* sin_t, int64_t B, int64_t H, int64_t d, int64_t rot,
+                   int64_t pos, int64_t Smax, int64_t ld_qkv, int mode, int dtype, void* stream);
+/* prefill: rotate K of the prompt rows and copy K,V into the cache (same layout as above). */
+int mm_kv_cache_fill(const void* k, const void* v, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
+                     int64_t B, int64_t H, int64_t S, int64_t d, int64_t rot, int64_t Smax, int64_t ld_qkv,
+                     int dtype, void* stream);
+
+/* ---- small fused elementwise pieces --------------------------------------------------------
+ * f32 -> bf16 cast with optional transposed copy (weights, once per optimizer step). */
+int mm_cast_f32_bf16(const float* x, void* y, void* y_t /*nullable, [cols][rows]*/, int64_t rows, int64_t cols,
+                     void* stream);
+/* argmax over the last dim of logits [rows][V] -> int64 ids (train_autoregressive.py:102). */
+int mm_argmax_rows(const void* logits, int64_t* out, int64_t rows, int64_t V, int64_t ld, int dtype, void* stream);
+
+/* OrthoGrad projection + AdamW, one fused pass per tensor list (ortho_grad.py:60-99 followed by
+ * torch.optim.AdamW.step).  Tensors are described by a device table of mm_param_desc. */
+typedef struct { float* p; float* g; float* m; float* v; int64_t n; } mm_param_desc;
+size_t mm_orthograd_adamw_workspace(int64_t n_tensors);
+int mm_orthograd_adamw(const mm_param_desc* host_descs, int64_t n_tensors, float lr, float beta1, float beta2,
+                       float adam_eps, float weight_decay, int64_t step, float ortho_eps, int rescale,
+                       int do_ortho, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,128 @@
+// Shared device/host helpers for libmmhip (gfx950 / CDNA4 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mmhip.h"
+
+typedef __hip_bfloat16 bf16;
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment, 8 bf16
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// ---------------------------------------------------------------- errors
+void mm_set_error(const char* fmt, ...);
+#define MM_FAIL(code, ...) do { mm_set_error(__VA_ARGS__); return (code); } while (0)
+#define MM_CHECK(cond, ...) do { if (!(cond)) MM_FAIL(MM_ERR_ARG, __VA_ARGS__); } while (0)
+#define MM_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) MM_FAIL(MM_ERR_LAUNCH, "%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- scalar conversion
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {           // round-to-nearest-even, NaN stays NaN
+    return __builtin_bit_cast(unsigned short, __float2bfloat16(f));
+}
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16 v) { return __bfloat162float(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return __float2bfloat16(v); }
+
+// ---------------------------------------------------------------- vector load/store of VEC elements -> float[VEC]
+template <typename T, int VEC> struct VecIO;
+template <> struct VecIO<float, 4> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct VecIO<float, 2> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[2]) {
+        float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[2]) {
+        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+};
+template <> struct VecIO<float, 1> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = *p; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[1]) { *p = v[0]; }
+};
+template <> struct VecIO<bf16, 8> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&v)[8]) {
+        uint4 t = *reinterpret_cast<const uint4*>(p);
+        unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float (&v)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+template <> struct VecIO<bf16, 4> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&v)[4]) {
+        uint2 t = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float (&v)[4]) {
+        uint2 t;
+        t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = t;
+    }
+};
+template <> struct VecIO<bf16, 2> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&v)[2]) {
+        unsigned t = *reinterpret_cast<const unsigned*>(p);
+        v[0] = __uint_as_float(t << 16); v[1] = __uint_as_float(t & 0xffff0000u); }
+    static __device__ __forceinline__ void store(bf16* p, const float (&v)[2]) {
+        *reinterpret_cast<unsigned*>(p) = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); }
+};
+template <> struct VecIO<bf16, 1> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&v)[1]) { v[0] = __bfloat162float(*p); }
+    static __device__ __forceinline__ void store(bf16* p, const float (&v)[1]) { *p = __float2bfloat16(v[0]); }
+};
+
+// ---------------------------------------------------------------- cross-lane sums (wave64, DPP for the in-row steps)
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// Sum over aligned groups of G consecutive lanes (G in 1,2,4,8,16,32,64); every lane of the group gets the sum.
+// All 64 lanes must be active.
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+    if (G >= 2) v += dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
+    if (G >= 4) v += dpp_f<0x4E>(v);        // quad_perm [2,3,0,1]
+    if (G >= 8) v += dpp_f<0x141>(v);       // row_half_mirror
+    if (G >= 16) v += dpp_f<0x140>(v);      // row_mirror
+    if (G >= 32) v += __shfl_xor(v, 16);
+    if (G >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+
+// Block-wide sum for blockDim.x == NW*64; red must hold NW floats; contains ONE __syncthreads().
+template <int NW> __device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; i++) t += red[i];
+    return t;
+}
+
+// exact-erf GELU (nn.GELU() default, reference models/convnext.py:30) and its derivative
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

@@ -1,0 +1,414 @@
+// MFMA GEMM family with fused epilogues:  out[M][N] = epi( A[M][K] . B[N][K]^T ).
+// Replaces nn.Linear / F.linear on the hot path (reference models/convnext.py:41,:43,:80,:134) and the
+// matmuls autograd derives from them (dX = dY.W, dW = dY^T.X).
+//
+// bf16: v_mfma_f32_16x16x32_bf16, f32 accumulate.   f32: v_mfma_f32_16x16x4_f32 (exact f32 FMA chains).
+// Tile BM x BN per 256-thread workgroup (4 waves as 2x2); operands are staged global -> registers -> LDS
+// (16-byte loads), the next K tile is fetched while the current one is multiplied.
+// Operand layouts: K-contiguous ([rows][K]) tiles are kept [rows][BK] in LDS and read with ds_read_b128;
+// K-major ([K][rows]) bf16 tiles are kept [BK][rows] and read with ds_read_b64_tr_b16 (hardware transpose),
+// so dX and dW products need no transposed copies in HBM.
+// The MFMA is issued as (B-fragment, A-fragment): D's register index then runs along N, so every lane
+// owns 4 consecutive output columns and the epilogue moves 8/16 bytes per lane.
+#include "common.h"
+
+struct GemmP {
+    const void* A; const void* B; void* out;
+    int M, N, K;
+    long lda, ldb, ldo;
+    const float* bias; void* pre; const void* mul; int act;
+    const float* gamma; const float* rowscale; int rows_per_scale;
+    const void* res;
+    int a_vec, b_vec, o_vec;       // 16-byte path legal for A / B loads, out-family accesses
+    int k_per_split;               // K range per blockIdx.z
+    float* partial;                // split-K slabs [z][M][N] (f32) or NULL
+    int tiles_m, tiles_n;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    static constexpr int BK = 64, EPV = 8;
+    static constexpr int PAD = 8;
+};
+template <> struct Mma<float> {
+    static constexpr int BK = 16, EPV = 4;
+    static constexpr int PAD = 1;
+};
+
+// ---- guarded EPV-wide global load into raw storage ------------------------------------------------
+template <typename T, int E>
+__device__ __forceinline__ void load_vec(const T* __restrict__ base, bool vec_ok, long slow, long slow_lim, long fast,
+                                         long fast_lim, long ld, T (&out)[E]) {
+    if (slow < slow_lim && vec_ok && fast + E <= fast_lim) {
+        typedef __attribute__((ext_vector_type(4))) unsigned u4;
+        *reinterpret_cast<u4*>(&out[0]) = *reinterpret_cast<const u4*>(base + slow * ld + fast);
+    } else {
+#pragma unroll
+        for (int j = 0; j < E; j++)
+            out[j] = (slow < slow_lim && fast + j < fast_lim) ? base[slow * ld + fast + j] : T(0.0f);
+    }
+}
+
+__device__ __forceinline__ float act_fwd(int act, float v) {
+    if (act == 1) return gelu_erf(v);
+    if (act == 2) { const float r = fmaxf(v, 0.f); return r * r; }
+    return v;
+}
+__device__ __forceinline__ float act_bwd(int act, float pre) {
+    if (act == 1) return gelu_erf_grad(pre);
+    if (act == 2) return 2.f * fmaxf(pre, 0.f);
+    return 1.f;
+}
+
+template <typename T, typename TO, int BM, int BN, bool AKM, bool BKM>
+__global__ __launch_bounds__(256) void gemm_k(const GemmP p) {
+    constexpr int BK = Mma<T>::BK, EPV = Mma<T>::EPV, PAD = Mma<T>::PAD;
+    constexpr bool IS_BF16 = sizeof(T) == 2;
+    // LDS images.  bf16: K-contiguous -> [ROWS][BK+PAD];  K-major -> [BK][ROWS+PAD].  f32: always [ROWS][BK+1].
+    constexpr int A_ELEMS = (IS_BF16 && AKM) ? BK * (BM + PAD) : BM * (BK + PAD);
+    constexpr int B_ELEMS = (IS_BF16 && BKM) ? BK * (BN + PAD) : BN * (BK + PAD);
+    __shared__ __attribute__((aligned(16))) T lds_a[A_ELEMS];
+    __shared__ __attribute__((aligned(16))) T lds_b[B_ELEMS];
+    constexpr int WM = BM / 2, WN = BN / 2;          // wave tile
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int NVA = BM * BK / EPV / 256, NVB = BN * BK / EPV / 256;
+    static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 threads");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware, bijective remap of the linear block id: each XCD (ids congruent mod 8) gets a contiguous
+    // run of tiles, so neighbouring tiles that share an operand panel share an L2
+    int wg;
+    {
+        const int nwg = p.tiles_m * p.tiles_n, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int tile_m = wg / p.tiles_n, tile_n = wg % p.tiles_n;
+    const long m0 = (long)tile_m * BM, n0 = (long)tile_n * BN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const T* __restrict__ A = (const T*)p.A;
+    const T* __restrict__ B = (const T*)p.B;
+
+    T ra[NVA][EPV], rb[NVB][EPV];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NVA; i++) {
+            const int v = tid + 256 * i;
+            if (!AKM) { const int row = v / (BK / EPV), kc = v % (BK / EPV);
+                load_vec<T, EPV>(A, p.a_vec, m0 + row, p.M, k0 + kc * EPV, kend, p.lda, ra[i]); }
+            else { const int k = v / (BM / EPV), rc = v % (BM / EPV);
+                load_vec<T, EPV>(A, p.a_vec, k0 + k, kend, m0 + rc * EPV, p.M, p.lda, ra[i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; i++) {
+            const int v = tid + 256 * i;
+            if (!BKM) { const int row = v / (BK / EPV), kc = v % (BK / EPV);
+                load_vec<T, EPV>(B, p.b_vec, n0 + row, p.N, k0 + kc * EPV, kend, p.ldb, rb[i]); }
+            else { const int k = v / (BN / EPV), rc = v % (BN / EPV);
+                load_vec<T, EPV>(B, p.b_vec, k0 + k, kend, n0 + rc * EPV, p.N, p.ldb, rb[i]); }
+        }
+    };
+    auto stash = [&]() {
+        typedef __attribute__((ext_vector_type(4))) unsigned u4;
+#pragma unroll
+        for (int i = 0; i < NVA; i++) {
+            const int v = tid + 256 * i;
+            if constexpr (IS_BF16) {
+                if (!AKM) { const int row = v / (BK / EPV), kc = v % (BK / EPV);
+                    *reinterpret_cast<u4*>(&lds_a[row * (BK + PAD) + kc * EPV]) = *reinterpret_cast<u4*>(&ra[i][0]); }
+                else { const int k = v / (BM / EPV), rc = v % (BM / EPV);
+                    *reinterpret_cast<u4*>(&lds_a[k * (BM + PAD) + rc * EPV]) = *reinterpret_cast<u4*>(&ra[i][0]); }
+            } else {
+                if (!AKM) { const int row = v / (BK / EPV), kc = v % (BK / EPV);
+#pragma unroll
+                    for (int j = 0; j < EPV; j++) lds_a[row * (BK + PAD) + kc * EPV + j] = ra[i][j]; }
+                else { const int k = v / (BM / EPV), rc = v % (BM / EPV);
+#pragma unroll
+                    for (int j = 0; j < EPV; j++) lds_a[(rc * EPV + j) * (BK + PAD) + k] = ra[i][j]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; i++) {
+            const int v = tid + 256 * i;
+            if constexpr (IS_BF16) {
+                if (!BKM) { const int row = v / (BK / EPV), kc = v % (BK / EPV);
+                    *reinterpret_cast<u4*>(&lds_b[row * (BK + PAD) + kc * EPV]) = *reinterpret_cast<u4*>(&rb[i][0]); }
+                else { const int k = v / (BN / EPV), rc = v % (BN / EPV);
+                    *reinterpret_cast<u4*>(&lds_b[k * (BN + PAD) + rc * EPV]) = *reinterpret_cast<u4*>(&rb[i][0]); }
+            } else {
+                if (!BKM) { const int row = v / (BK / EPV), kc = v % (BK / EPV);
+#pragma unroll
+                    for (int j = 0; j < EPV; j++) lds_b[row * (BK + PAD) + kc * EPV + j] = rb[i][j]; }
+                else { const int k = v / (BN / EPV), rc = v % (BN / EPV);
+#pragma unroll
+                    for (int j = 0; j < EPV; j++) lds_b[(rc * EPV + j) * (BK + PAD) + k] = rb[i][j]; }
+            }
+        }
+    };
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;           // fragment row, k group
+    fetch(kbeg);
+    stash();
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more) fetch(k0 + BK);
+        if constexpr (IS_BF16) {
+            typedef bf16x4_t __attribute__((address_space(3))) * lds4p;
+#pragma unroll
+            for (int ks = 0; ks < BK / 32; ks++) {
+                bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    const int r0 = wm * WM + i * 16;
+                    if (!AKM) fa[i] = *reinterpret_cast<const bf16x8_t*>(&lds_a[(r0 + fr) * (BK + PAD) + ks * 32 + fg * 8]);
+                    else {
+                        const int q = fr >> 2, pp = fr & 3;
+                        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (lds4p)(&lds_a[(ks * 32 + fg * 8 + q) * (BM + PAD) + r0 + 4 * pp]));
+                        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (lds4p)(&lds_a[(ks * 32 + fg * 8 + 4 + q) * (BM + PAD) + r0 + 4 * pp]));
+                        fa[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    const int r0 = wn * WN + j * 16;
+                    if (!BKM) fb[j] = *reinterpret_cast<const bf16x8_t*>(&lds_b[(r0 + fr) * (BK + PAD) + ks * 32 + fg * 8]);
+                    else {
+                        const int q = fr >> 2, pp = fr & 3;
+                        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (lds4p)(&lds_b[(ks * 32 + fg * 8 + q) * (BN + PAD) + r0 + 4 * pp]));
+                        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (lds4p)(&lds_b[(ks * 32 + fg * 8 + 4 + q) * (BN + PAD) + r0 + 4 * pp]));
+                        fb[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < BK / 4; ks++) {
+                float fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; i++) fa[i] = lds_a[(wm * WM + i * 16 + fr) * (BK + PAD) + ks * 4 + fg];
+#pragma unroll
+                for (int j = 0; j < TN; j++) fb[j] = lds_b[(wn * WN + j * 16 + fr) * (BK + PAD) + ks * 4 + fg];
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) { stash(); __syncthreads(); }
+    }
+
+    // ---- epilogue: lane owns columns n..n+3 of row m for each (i,j) tile
+    TO* __restrict__ out = (TO*)p.out;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const long m = m0 + wm * WM + i * 16 + fr;
+        if (m >= p.M) continue;
+        const float rscale = p.rowscale ? p.rowscale[m / p.rows_per_scale] : 1.f;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const long n = n0 + wn * WN + j * 16 + fg * 4;
+            if (n >= p.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.partial) {
+                float* dst = p.partial + ((long)blockIdx.z * p.M + m) * p.N + n;
+#pragma unroll
+                for (int e = 0; e < 4; e++) if (n + e < p.N) dst[e] = v[e];
+                continue;
+            }
+            const bool full = p.o_vec && n + 4 <= p.N;
+            const long off = m * p.ldo + n;
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) if (n + e < p.N) v[e] += p.bias[n + e];
+            }
+            if (p.pre) {
+                TO* pre = (TO*)p.pre;
+                if (full) VecIO<TO, 4>::store(pre + off, v);
+                else { for (int e = 0; e < 4; e++) if (n + e < p.N) pre[off + e] = from_f<TO>(v[e]); }
+            }
+            if (p.mul) {
+                const TO* mul = (const TO*)p.mul;
+                float h[4] = {0.f, 0.f, 0.f, 0.f};
+                if (full) VecIO<TO, 4>::load(mul + off, h);
+                else { for (int e = 0; e < 4; e++) if (n + e < p.N) h[e] = to_f(mul[off + e]); }
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] *= act_bwd(p.act, h[e]);
+            } else if (p.act) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = act_fwd(p.act, v[e]);
+            }
+            if (p.gamma) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) if (n + e < p.N) v[e] *= p.gamma[n + e];
+            }
+            if (p.rowscale) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] *= rscale;
+            }
+            if (p.res) {
+                const TO* res = (const TO*)p.res;
+                float h[4] = {0.f, 0.f, 0.f, 0.f};
+                if (full) VecIO<TO, 4>::load(res + off, h);
+                else { for (int e = 0; e < 4; e++) if (n + e < p.N) h[e] = to_f(res[off + e]); }
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] += h[e];
+            }
+            if (full) VecIO<TO, 4>::store(out + off, v);
+            else { for (int e = 0; e < 4; e++) if (n + e < p.N) out[off + e] = from_f<TO>(v[e]); }
+        }
+    }
+}
+
+// split-K second stage: out[m][n] = sum_z partial[z][m][n] (+ bias), fixed order
+template <typename TO>
+__global__ void splitk_reduce_k(const float* __restrict__ partial, int splits, long MN, int N, long ldo,
+                                const float* __restrict__ bias, TO* __restrict__ out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= MN) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; z++) s += partial[(long)z * MN + idx];
+    const long m = idx / N; const int n = (int)(idx % N);
+    if (bias) s += bias[n];
+    out[m * ldo + n] = from_f<TO>(s);
+}
+
+template <typename T, typename TO, int BM, int BN>
+static void launch_layout(const GemmP& p, int akm, int bkm, dim3 grid, hipStream_t st) {
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_k<T, TO, BM, BN, false, false>), grid, dim3(256), 0, st, p);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_k<T, TO, BM, BN, false, true>), grid, dim3(256), 0, st, p);
+    else if (akm && bkm) hipLaunchKernelGGL((gemm_k<T, TO, BM, BN, true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_k<T, TO, BM, BN, true, false>), grid, dim3(256), 0, st, p);
+}
+
+template <typename T, typename TO>
+static void launch_tile(GemmP& p, int akm, int bkm, int splits, hipStream_t st) {
+    // big tile when it still fills the chip, else 64x64
+    const long t128 = cdiv(p.M, 128) * cdiv(p.N, 128) * splits;
+    if (t128 >= 256) {
+        p.tiles_m = (int)cdiv(p.M, 128); p.tiles_n = (int)cdiv(p.N, 128);
+        launch_layout<T, TO, 128, 128>(p, akm, bkm, dim3((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)splits), st);
+    } else {
+        p.tiles_m = (int)cdiv(p.M, 64); p.tiles_n = (int)cdiv(p.N, 64);
+        launch_layout<T, TO, 64, 64>(p, akm, bkm, dim3((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)splits), st);
+    }
+}
+
+extern "C" int mm_gemm(const mm_gemm_args* a, void* stream) {
+    MM_CHECK(a && a->A && a->B && a->out, "gemm: null pointer");
+    MM_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gemm: empty shape M=%lld N=%lld K=%lld", (long long)a->M, (long long)a->N, (long long)a->K);
+    MM_CHECK(a->M < (1LL << 31) && a->N < (1LL << 31) && a->K < (1LL << 31), "gemm: dimension too large");
+    MM_CHECK(a->dtype == MM_F32 || a->dtype == MM_BF16, "gemm: bad dtype %d", a->dtype);
+    MM_CHECK(a->out_dtype == MM_F32 || a->out_dtype == MM_BF16, "gemm: bad out_dtype %d", a->out_dtype);
+    MM_CHECK(a->act >= 0 && a->act <= 2, "gemm: bad act %d", a->act);
+    MM_CHECK(a->lda >= (a->a_kmajor ? a->M : a->K) && a->ldb >= (a->b_kmajor ? a->N : a->K) && a->ldo >= a->N,
+             "gemm: leading dimension smaller than the row length");
+    MM_CHECK(!a->rowscale || a->rows_per_scale > 0, "gemm: rowscale needs rows_per_scale > 0");
+    const int esz = a->dtype == MM_BF16 ? 2 : 4;
+    const int epv = 16 / esz;
+    GemmP p{};
+    p.A = a->A; p.B = a->B; p.out = a->out;
+    p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
+    p.lda = a->lda; p.ldb = a->ldb; p.ldo = a->ldo;
+    p.bias = a->bias; p.pre = a->pre; p.mul = a->mul; p.act = a->act;
+    p.gamma = a->gamma; p.rowscale = a->rowscale; p.rows_per_scale = (int)a->rows_per_scale;
+    p.res = a->res;
+    p.a_vec = (a->lda % epv == 0) && (((uintptr_t)a->A) % 16 == 0);
+    p.b_vec = (a->ldb % epv == 0) && (((uintptr_t)a->B) % 16 == 0);
+    const int osz = a->out_dtype == MM_BF16 ? 2 : 4;
+    auto al = [&](const void* q) { return q == nullptr || ((uintptr_t)q) % (4 * osz) == 0; };
+    p.o_vec = (a->ldo % 4 == 0) && al(a->out) && al(a->pre) && al(a->mul) && al(a->res);
+    int splits = a->split_k > 1 ? a->split_k : 1;
+    const int bk = a->dtype == MM_BF16 ? 64 : 16;
+    if (splits > 1) {
+        MM_CHECK(!a->pre && !a->mul && !a->act && !a->gamma && !a->rowscale && !a->res, "gemm: split_k supports only the bias epilogue");
+        MM_CHECK(a->workspace && a->workspace_bytes >= (size_t)splits * a->M * a->N * sizeof(float), "gemm: split_k workspace too small");
+        int64_t per = cdiv(cdiv(a->K, splits), bk) * bk;
+        splits = (int)cdiv(a->K, per);
+        p.k_per_split = (int)per;
+        p.partial = splits > 1 ? (float*)a->workspace : nullptr;
+    } else {
+        p.k_per_split = p.K;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == MM_BF16) {
+        if (a->out_dtype == MM_BF16) launch_tile<bf16, bf16>(p, a->a_kmajor, a->b_kmajor, splits, st);
+        else launch_tile<bf16, float>(p, a->a_kmajor, a->b_kmajor, splits, st);
+    } else {
+        MM_CHECK(a->out_dtype == MM_F32, "gemm: f32 operands need an f32 output");
+        launch_tile<float, float>(p, a->a_kmajor, a->b_kmajor, splits, st);
+    }
+    MM_LAUNCH_CHECK();
+    if (p.partial) {
+        const long MN = (long)a->M * a->N;
+        const dim3 grid((unsigned)cdiv(MN, 256));
+        if (a->out_dtype == MM_BF16)
+            hipLaunchKernelGGL(splitk_reduce_k<bf16>, grid, dim3(256), 0, st, p.partial, splits, MN, p.N, p.ldo, p.bias, (bf16*)p.out);
+        else
+            hipLaunchKernelGGL(splitk_reduce_k<float>, grid, dim3(256), 0, st, p.partial, splits, MN, p.N, p.ldo, p.bias, (float*)p.out);
+        MM_LAUNCH_CHECK();
+    }
+    return MM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums (bias gradients): two-stage, fixed order.  workspace [nchunks][N] floats.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void colsum_stage1_k(const T* __restrict__ x, float* __restrict__ part, int M, int N, long ld, int rows_per_chunk) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    float s = 0.f;
+    for (int r = r0; r < r1; r++) s += to_f(x[(long)r * ld + n]);
+    part[(long)blockIdx.y * N + n] = s;
+}
+__global__ void colsum_stage2_k(const float* __restrict__ part, float* __restrict__ out, int nchunks, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; c++) s += part[(long)c * N + n];
+    out[n] = s;
+}
+static int colsum_chunks(int64_t M) { int64_t c = cdiv(M, 64); if (c > 256) c = 256; if (c < 1) c = 1; return (int)c; }
+extern "C" size_t mm_colsum_workspace(int64_t M, int64_t N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (size_t)colsum_chunks(M) * (size_t)N * sizeof(float);
+}
+extern "C" int mm_colsum(const void* x, float* out, void* workspace, size_t workspace_bytes, int64_t M, int64_t N,
+                         int64_t ld, int dtype, void* stream) {
+    MM_CHECK(x && out && workspace, "colsum: null pointer");
+    MM_CHECK(M > 0 && N > 0 && ld >= N, "colsum: bad shape");
+    MM_CHECK(workspace_bytes >= mm_colsum_workspace(M, N), "colsum: workspace too small");
+    const int chunks = colsum_chunks(M);
+    const int rpc = (int)cdiv(M, chunks);
+    const int nchunks = (int)cdiv(M, rpc);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)cdiv(N, 256), (unsigned)nchunks);
+    if (dtype == MM_F32) hipLaunchKernelGGL(colsum_stage1_k<float>, grid, dim3(256), 0, st, (const float*)x, (float*)workspace, (int)M, (int)N, (long)ld, rpc);
+    else if (dtype == MM_BF16) hipLaunchKernelGGL(colsum_stage1_k<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (float*)workspace, (int)M, (int)N, (long)ld, rpc);
+    else MM_FAIL(MM_ERR_ARG, "colsum: bad dtype %d", dtype);
+    MM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_stage2_k, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, (const float*)workspace, out, nchunks, (int)N);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}

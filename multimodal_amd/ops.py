@@ -1,0 +1,222 @@
+"""Thin Python wrappers over the C ABI (include/mmhip.h): shape/dtype/contiguity checks live here,
+PyTorch only provides device memory and the current stream.  No fallbacks: CPU tensors raise."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+
+def _chk(t: Tensor, name: str, dtype=None) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the hot path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _f32(t: Tensor, name: str) -> Tensor:
+    return _chk(t, name, torch.float32)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device, tag: str = "ws") -> Tensor:
+    """Grow-only byte workspace per (device, tag); the caller owns it, the library never allocates."""
+    key = (device, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------- K1
+def dwconv7_ln_fwd(x: Tensor, w: Tensor, b: Tensor, ln_w: Tensor, ln_b: Tensor, eps: float = 1e-5,
+                   layout: int = L.LAYOUT_BLC, save_stats: bool = False):
+    """x: [B,L,C] (BLC) or [B,C,L] (BCL) -> y [B,L,C] (+ mean, rstd [B*L])."""
+    _chk(x, "x")
+    if layout == L.LAYOUT_BLC:
+        B, Ln, Cc = x.shape
+    else:
+        B, Cc, Ln = x.shape
+    w2 = _f32(w, "dwconv.weight").view(Cc, 7)
+    y = torch.empty((B, Ln, Cc), dtype=x.dtype, device=x.device)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(B * Ln, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+    L.check(L.lib().mm_dwconv7_ln_fwd(L.ptr(x), L.ptr(w2), L.ptr(_f32(b, "b")), L.ptr(_f32(ln_w, "ln_w")),
+                                      L.ptr(_f32(ln_b, "ln_b")), L.ptr(y), L.ptr(mean), L.ptr(rstd), B, Cc, Ln, eps,
+                                      L.dtype_code(x), layout, L.cur_stream()), "mm_dwconv7_ln_fwd")
+    return y, mean, rstd
+
+
+def dwconv7_ln_bwd(x: Tensor, dy: Tensor, dres: Optional[Tensor], w: Tensor, b: Tensor, ln_w: Tensor, mean: Tensor,
+                   rstd: Tensor):
+    _chk(x, "x"); _chk(dy, "dy", x.dtype)
+    B, Ln, Cc = x.shape
+    dx = torch.empty_like(x)
+    dw = torch.empty((Cc, 1, 7), dtype=torch.float32, device=x.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    dlw = torch.empty_like(db)
+    dlb = torch.empty_like(db)
+    nbytes = L.lib().mm_dwconv7_ln_bwd_workspace(B, Cc, Ln)
+    ws = workspace(nbytes, x.device)
+    if dres is not None:
+        _chk(dres, "dres", x.dtype)
+    L.check(L.lib().mm_dwconv7_ln_bwd(L.ptr(x), L.ptr(dy), L.ptr(dres), L.ptr(_f32(w, "w").view(Cc, 7)), L.ptr(b),
+                                      L.ptr(ln_w), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(dlw),
+                                      L.ptr(dlb), L.ptr(ws), nbytes, B, Cc, Ln, L.dtype_code(x), L.cur_stream()),
+            "mm_dwconv7_ln_bwd")
+    return dx, dw, db, dlw, dlb
+
+
+# --------------------------------------------------------------------------- stem
+def stem_ln_fwd(x: Tensor, w: Tensor, b: Tensor, ln_w: Tensor, ln_b: Tensor, out_dtype, eps: float = 1e-5,
+                save_stats: bool = False):
+    """x: f32 [B,Lin] -> y [B,Lo,C0]."""
+    _f32(x, "ir")
+    B, Lin = x.shape
+    C0 = w.shape[0]
+    Lo = (Lin - 4) // 4 + 1
+    y = torch.empty((B, Lo, C0), dtype=out_dtype, device=x.device)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(B * Lo, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+    L.check(L.lib().mm_stem_ln_fwd(L.ptr(x), L.ptr(_f32(w, "w").view(C0, 4)), L.ptr(_f32(b, "b")), L.ptr(_f32(ln_w, "ln_w")),
+                                   L.ptr(_f32(ln_b, "ln_b")), L.ptr(y), L.ptr(mean), L.ptr(rstd), B, Lin, C0, eps,
+                                   L.dtype_code(y), L.cur_stream()), "mm_stem_ln_fwd")
+    return y, mean, rstd
+
+
+def stem_ln_bwd(x: Tensor, dy: Tensor, w: Tensor, b: Tensor, ln_w: Tensor, mean: Tensor, rstd: Tensor, need_dx: bool):
+    B, Lin = x.shape
+    C0 = w.shape[0]
+    _chk(dy, "dy")
+    dx = torch.zeros_like(x) if need_dx else None
+    dw = torch.empty((C0, 1, 4), dtype=torch.float32, device=x.device)
+    db = torch.empty(C0, dtype=torch.float32, device=x.device)
+    dlw = torch.empty_like(db)
+    dlb = torch.empty_like(db)
+    nbytes = L.lib().mm_stem_ln_bwd_workspace(B, Lin, C0)
+    ws = workspace(nbytes, x.device)
+    L.check(L.lib().mm_stem_ln_bwd(L.ptr(x), L.ptr(dy), L.ptr(w.view(C0, 4)), L.ptr(b), L.ptr(ln_w), L.ptr(mean), L.ptr(rstd),
+                                   L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(dlw), L.ptr(dlb), L.ptr(ws), nbytes, B, Lin, C0,
+                                   L.dtype_code(dy), L.cur_stream()), "mm_stem_ln_bwd")
+    return dx, dw, db, dlw, dlb
+
+
+# --------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5, save_stats: bool = False,
+                  drop_tail_to: Optional[int] = None):
+    """x: [..., C] -> LN over C.  With drop_tail_to=Lout and x [G,Lin,C]: y is [G,Lout,C] (rows l>=Lout dropped)."""
+    _chk(x, "x")
+    Cc = x.shape[-1]
+    if drop_tail_to is None:
+        rows = x.numel() // Cc
+        G, Lin, Lout = 1, rows, rows
+        y = torch.empty_like(x)
+    else:
+        G, Lin, _ = x.shape
+        Lout = drop_tail_to
+        y = torch.empty((G, Lout, Cc), dtype=x.dtype, device=x.device)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(G * Lout, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+    L.check(L.lib().mm_layernorm_fwd(L.ptr(x), L.ptr(_f32(w, "ln.weight")), L.ptr(_f32(b, "ln.bias")), L.ptr(y), L.ptr(mean),
+                                     L.ptr(rstd), G, Lin, Lout, Cc, eps, L.dtype_code(x), L.cur_stream()), "mm_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(x: Tensor, dy: Tensor, dres: Optional[Tensor], w: Tensor, mean: Tensor, rstd: Tensor,
+                  drop_tail_to: Optional[int] = None):
+    _chk(x, "x"); _chk(dy, "dy", x.dtype)
+    Cc = x.shape[-1]
+    if drop_tail_to is None:
+        rows = x.numel() // Cc
+        G, Lin, Lout = 1, rows, rows
+    else:
+        G, Lin, _ = x.shape
+        Lout = drop_tail_to
+    dx = torch.empty_like(x)
+    dw = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    db = torch.empty_like(dw)
+    nbytes = L.lib().mm_layernorm_bwd_workspace(G * Lin, Cc)
+    ws = workspace(nbytes, x.device)
+    if dres is not None:
+        _chk(dres, "dres", x.dtype)
+    L.check(L.lib().mm_layernorm_bwd(L.ptr(x), L.ptr(dy), L.ptr(dres), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(dw),
+                                     L.ptr(db), L.ptr(ws), nbytes, G, Lin, Lout, Cc, L.dtype_code(x), L.cur_stream()),
+            "mm_layernorm_bwd")
+    return dx, dw, db
+
+
+# --------------------------------------------------------------------------- GEMM
+ACT_NONE, ACT_GELU, ACT_RELU2 = 0, 1, 2
+
+
+def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool = False, b_kmajor: bool = False,
+         out_dtype=None, bias: Optional[Tensor] = None, pre: Optional[Tensor] = None, mul: Optional[Tensor] = None,
+         act: int = ACT_NONE, gamma: Optional[Tensor] = None, rowscale: Optional[Tensor] = None, rows_per_scale: int = 0,
+         res: Optional[Tensor] = None, out: Optional[Tensor] = None, split_k: int = 1) -> Tensor:
+    """out[M,N] = epilogue(A[M,K] @ B[N,K]^T).  A is [M,K] (or [K,M] if a_kmajor); B is [N,K] (or [K,N] if b_kmajor).
+    Both operands are 2-D views with unit stride in the last dim."""
+    for t, nm in ((A, "A"), (B, "B")):
+        if not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError(f"gemm: {nm} must be a 2-D GPU tensor with unit inner stride")
+    if A.dtype != B.dtype:
+        raise TypeError(f"gemm: operand dtypes differ ({A.dtype} vs {B.dtype})")
+    exp_a = (K, M) if a_kmajor else (M, K)
+    exp_b = (K, N) if b_kmajor else (N, K)
+    if tuple(A.shape) != exp_a or tuple(B.shape) != exp_b:
+        raise RuntimeError(f"gemm: shapes {tuple(A.shape)} / {tuple(B.shape)} do not match M={M} N={N} K={K}")
+    out_dtype = out_dtype or A.dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    ldo = out.stride(0)
+    for t, nm in ((pre, "pre"), (mul, "mul"), (res, "res")):
+        if t is not None and (t.dtype != out.dtype or t.stride(-1) != 1 or t.stride(-2) != ldo or t.numel() != M * N):
+            raise RuntimeError(f"gemm: {nm} must look like out ([M,N] {out.dtype}, ld {ldo})")
+    a = L.GemmArgs()
+    a.A, a.B, a.out = L.ptr(A), L.ptr(B), L.ptr(out)
+    a.M, a.N, a.K = M, N, K
+    a.lda, a.ldb, a.ldo = A.stride(0), B.stride(0), ldo
+    a.a_kmajor, a.b_kmajor = int(a_kmajor), int(b_kmajor)
+    a.dtype, a.out_dtype = L.dtype_code(A), L.dtype_code(out)
+    a.bias = L.ptr(_f32(bias, "bias")) if bias is not None else None
+    a.pre = L.ptr(pre); a.mul = L.ptr(mul); a.act = act
+    a.gamma = L.ptr(_f32(gamma, "gamma")) if gamma is not None else None
+    a.rowscale = L.ptr(_f32(rowscale, "rowscale")) if rowscale is not None else None
+    a.rows_per_scale = rows_per_scale
+    a.res = L.ptr(res)
+    a.split_k = split_k
+    if split_k > 1:
+        nbytes = split_k * M * N * 4
+        ws = workspace(nbytes, A.device, "gemm")
+        a.workspace, a.workspace_bytes = L.ptr(ws), nbytes
+    L.check(L.lib().mm_gemm(C.byref(a), L.cur_stream()), "mm_gemm")
+    return out
+
+
+def colsum(x: Tensor, M: int, N: int) -> Tensor:
+    if not x.is_cuda or x.stride(-1) != 1:
+        raise RuntimeError("colsum: expected a GPU tensor with unit inner stride")
+    x2 = x.reshape(M, N) if x.is_contiguous() else x
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    nbytes = L.lib().mm_colsum_workspace(M, N)
+    ws = workspace(nbytes, x.device)
+    L.check(L.lib().mm_colsum(L.ptr(x2), L.ptr(out), L.ptr(ws), nbytes, M, N, x2.stride(0), L.dtype_code(x), L.cur_stream()),
+            "mm_colsum")
+    return out
