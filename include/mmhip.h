@@ -124,10 +124,14 @@ int mm_colsum(const void* x, float* out, void* workspace, size_t workspace_bytes
 int mm_prefix_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* cos_t,
                        const float* sin_t, int64_t B, int64_t H, int64_t S, int64_t d, int64_t rot,
                        int64_t prompt_len, int64_t ld_qkv, int mode, int dtype, void* stream);
+/* backward of the above (autograd of transformer_decoder.py:129-153): dq,dk,dv are gradients w.r.t. the
+ * UN-rotated q,k,v, laid out [B][S][H][d] with row stride ld_dqkv; o,d_o are [B][S][H][d] contiguous.
+ * workspace: mm_prefix_attn_bwd_workspace(B,H,S) bytes (row sums of dO*O).  Deterministic, no atomics. */
+size_t mm_prefix_attn_bwd_workspace(int64_t B, int64_t H, int64_t S);
 int mm_prefix_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
-                       void* dq, void* dk, void* dv, const float* cos_t, const float* sin_t, int64_t B, int64_t H,
-                       int64_t S, int64_t d, int64_t rot, int64_t prompt_len, int64_t ld_qkv, int64_t ld_dqkv,
-                       int mode, int dtype, void* stream);
+                       void* dq, void* dk, void* dv, const float* cos_t, const float* sin_t, void* workspace,
+                       size_t workspace_bytes, int64_t B, int64_t H, int64_t S, int64_t d, int64_t rot,
+                       int64_t prompt_len, int64_t ld_qkv, int64_t ld_dqkv, int mode, int dtype, void* stream);
 
 /* ---- K4: one decode step of attention against a KV cache ----------------------------------
  * no counterpart in the reference (it recomputes the full decoder every step,

@@ -56,12 +56,13 @@ _SIGNATURES = {
     "mm_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "mm_colsum_workspace": (sz, [i64, i64]),
     "mm_colsum": (i32, [vp, vp, vp, sz, i64, i64, i64, i32, vp]),
-}
-_PENDING = {
     "mm_prefix_attn_fwd": (i32, [vp] * 7 + [i64] * 7 + [i32, i32, vp]),
-    "mm_prefix_attn_bwd": (i32, [vp] * 11 + [i64] * 8 + [i32, i32, vp]),
+    "mm_prefix_attn_bwd_workspace": (sz, [i64, i64, i64]),
+    "mm_prefix_attn_bwd": (i32, [vp] * 11 + [vp, sz] + [i64] * 8 + [i32, i32, vp]),
     "mm_decode_attn": (i32, [vp] * 8 + [i64] * 7 + [i32, i32, vp]),
     "mm_kv_cache_fill": (i32, [vp] * 6 + [i64] * 7 + [i32, vp]),
+}
+_PENDING = {
     "mm_cast_f32_bf16": (i32, [vp, vp, vp, i64, i64, vp]),
     "mm_argmax_rows": (i32, [vp, vp, i64, i64, i64, i32, vp]),
     "mm_orthograd_adamw_workspace": (sz, [i64]),

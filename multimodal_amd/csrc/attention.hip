@@ -1,0 +1,915 @@
+// K3 / K3b / K4: prefix-LM attention with partial RoPE, softmax or stablemax, on the matrix cores.
+// Replaces reference models/transformer_decoder.py:129-153 (RoPE, scores, mask, stablemax|SDPA, @v), the
+// [B,H,S,S] boolean mask of :295-298 (evaluated in-kernel from indices) and their autograd; K4 is the
+// KV-cached decode step the reference does not have (train_autoregressive.py:97-101 recomputes everything).
+//
+// Layout: q,k,v,o are [B][S][H][d] (row stride ld elements), i.e. the nn.Linear outputs as they are.
+// One workgroup = one (b,h) and 64 queries (4 waves x 16).  K/V tiles of KT keys are staged in LDS and
+// shared by the 4 waves.  Products are computed TRANSPOSED so the query index sits on the lane for both:
+//   S^T[key][q]  = mfma(K rows, Q rows)           (lane = q, registers = 4 keys)
+//   O^T[dv][q]  += mfma(V^T (ds_read_b64_tr_b16), P^T straight from the S^T accumulator registers)
+// hence the per-query softmax/stablemax state never crosses lanes except for one 4-lane sum, and no
+// [S,S] score tensor ever exists in HBM (the reference materialises ~7 of them).
+#include "common.h"
+#include <type_traits>
+
+struct AttnP {
+    const void* q; const void* k; const void* v; void* o; float* lse;
+    const void* dO; void* dq; void* dk; void* dv; const float* delta;
+    const float* cos_t; const float* sin_t;
+    int B, H, S, d, rot, P;
+    long ld, ld_o, ld_d;
+    float scale;
+    int vec_ok;
+};
+
+template <typename T> struct AT;
+template <> struct AT<bf16> { static constexpr int KT = 32, PAD = 8, KSTEP = 32; };
+template <> struct AT<float> { static constexpr int KT = 16, PAD = 2, KSTEP = 4; };
+
+// stage `nrows` rows (row0..) of a [S][d] head slice into LDS [nrows][pitch], zero padded to DP columns
+template <typename T, int DP>
+__device__ __forceinline__ void stage_rows(T* lds, int pitch, const T* __restrict__ g, long ld, int row0, int nrows,
+                                           int S, int d, bool vec_ok) {
+    constexpr int V4 = DP / 4;
+    for (int idx = threadIdx.x; idx < nrows * V4; idx += blockDim.x) {
+        const int r = idx / V4, c = (idx % V4) * 4;
+        const int row = row0 + r;
+        alignas(16) T v[4];
+        if (row < S && c < d) {
+            const T* src = g + (long)row * ld + c;
+            if (vec_ok && c + 4 <= d) {
+                if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(v) = *reinterpret_cast<const uint2*>(src);
+                else *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(src);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = (c + j < d) ? src[j] : T(0.0f);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = T(0.0f);
+        }
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(&lds[r * pitch + c]) = *reinterpret_cast<uint2*>(v);
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) lds[r * pitch + c + j] = v[j];
+        }
+    }
+}
+
+// NeoX half rotation of the first `rot` columns of rows staged in LDS; row r sits at absolute position row0+r.
+// inverse=true applies the transpose (for gradients).
+template <typename T>
+__device__ __forceinline__ void rope_rows(T* lds, int pitch, int row0, int nrows, int S, int rot,
+                                          const float* __restrict__ cos_t, const float* __restrict__ sin_t, bool inverse) {
+    const int half = rot >> 1;
+    for (int idx = threadIdx.x; idx < nrows * half; idx += blockDim.x) {
+        const int r = idx / half, i = idx % half;
+        const int pos = row0 + r;
+        if (pos < S) {
+            const float c = cos_t[(long)pos * half + i];
+            float s = sin_t[(long)pos * half + i];
+            if (inverse) s = -s;
+            const float a = to_f(lds[r * pitch + i]), b = to_f(lds[r * pitch + i + half]);
+            lds[r * pitch + i] = from_f<T>(a * c - b * s);
+            lds[r * pitch + i + half] = from_f<T>(b * c + a * s);
+        }
+    }
+}
+
+__device__ __forceinline__ bool attn_allowed(int qi, int kj, int P, int S) {
+    return kj < S && (kj <= qi || (qi < P && kj < P));
+}
+__device__ __forceinline__ float stable_s_f(float x) { return x < 0.f ? 1.0f / ((1.0f - x) + 1e-9f) : x + 1.0f; }
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <typename T, int DP, bool STABLE>
+__global__ __launch_bounds__(256) void prefix_attn_fwd_k(const AttnP p) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int KT = AT<T>::KT, PITCH = DP + AT<T>::PAD, KSTEP = AT<T>::KSTEP;
+    constexpr int NKS = DP / KSTEP;          // k-steps of the QK^T product
+    constexpr int NDV = DP / 16;             // output dv tiles
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* lk = reinterpret_cast<T*>(smem);
+    T* lv = lk + KT * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = blockIdx.x * 64;
+    const long head_off = (long)b * p.S * p.ld + (long)h * p.d;
+    const T* qg = (const T*)p.q + head_off;
+    const T* kg = (const T*)p.k + head_off;
+    const T* vg = (const T*)p.v + head_off;
+
+    // ---- Q fragments of this wave's 16 queries (rotated), staged through LDS one wave at a time
+    typedef typename std::conditional<BF, bf16x8_t, float>::type Frag;
+    Frag qf[NKS];
+    for (int w = 0; w < 4; w++) {
+        stage_rows<T, DP>(lk, PITCH, qg, p.ld, q0 + 16 * w, 16, p.S, p.d, p.vec_ok);
+        __syncthreads();
+        rope_rows<T>(lk, PITCH, q0 + 16 * w, 16, p.S, p.rot, p.cos_t, p.sin_t, false);
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                if constexpr (BF) qf[ks] = *reinterpret_cast<const bf16x8_t*>(&lk[fr * PITCH + ks * 32 + fg * 8]);
+                else qf[ks] = lk[fr * PITCH + ks * 4 + fg];
+            }
+        }
+        __syncthreads();
+    }
+
+    const int qw0 = q0 + 16 * wave;                 // first query of this wave
+    const int qi = qw0 + fr;                        // this lane's query
+    auto key_end = [&](int qlo, int qhi) {          // one past the last key any query in [qlo,qhi] may see
+        int e = min(qhi, p.S - 1) + 1;
+        if (qlo < p.P) e = max(e, p.P);
+        return min(e, p.S);
+    };
+    const int kend_blk = key_end(q0, q0 + 63);
+    const int kend_w = (qw0 < p.S) ? key_end(qw0, qw0 + 15) : 0;
+
+    f32x4_t oacc[NDV];
+#pragma unroll
+    for (int n = 0; n < NDV; n++) oacc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = 0; k0 < kend_blk; k0 += KT) {
+        stage_rows<T, DP>(lk, PITCH, kg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP>(lv, PITCH, vg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
+        __syncthreads();
+        rope_rows<T>(lk, PITCH, k0, KT, p.S, p.rot, p.cos_t, p.sin_t, false);
+        __syncthreads();
+        if (k0 < kend_w) {                           // wave-uniform
+            if constexpr (BF) {
+                f32x4_t sacc[2];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    sacc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ks++) {
+                        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&lk[(16 * t + fr) * PITCH + ks * 32 + fg * 8]);
+                        sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sacc[t], 0, 0, 0);
+                    }
+                }
+                float pv[8];
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int kj = k0 + 16 * t + 4 * fg + r;
+                        const float x = sacc[t][r] * p.scale;
+                        const bool ok = attn_allowed(qi, kj, p.P, p.S);
+                        if (STABLE) pv[4 * t + r] = ok ? stable_s_f(x) : 0.f;
+                        else { pv[4 * t + r] = ok ? x : -INFINITY; tmax = fmaxf(tmax, pv[4 * t + r]); }
+                    }
+                if (!STABLE) {
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                    const float m_new = fmaxf(m_run, tmax);
+                    const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int n = 0; n < NDV; n++) oacc[n] *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) pv[e] = (m_new == -INFINITY) ? 0.f : __expf(pv[e] - m_new);
+                    m_run = m_new;
+                }
+                bf16x8_t pf;
+#pragma unroll
+                for (int e = 0; e < 8; e++) { l_run += pv[e]; pf[e] = (short)f2bf(pv[e]); }
+                typedef bf16x4_t __attribute__((address_space(3))) * lds4p;
+                const int qq = fr >> 2, pp = fr & 3;
+#pragma unroll
+                for (int n = 0; n < NDV; n++) {
+                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lv[(4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lv[(16 + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                    const bf16x8_t vf = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    oacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[n], 0, 0, 0);
+                }
+            } else {
+                f32x4_t sacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ks++)
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(lk[fr * PITCH + ks * 4 + fg], qf[ks], sacc, 0, 0, 0);
+                float pv[4];
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int kj = k0 + 4 * fg + r;
+                    const float x = sacc[r] * p.scale;
+                    const bool ok = attn_allowed(qi, kj, p.P, p.S);
+                    if (STABLE) pv[r] = ok ? stable_s_f(x) : 0.f;
+                    else { pv[r] = ok ? x : -INFINITY; tmax = fmaxf(tmax, pv[r]); }
+                }
+                if (!STABLE) {
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                    const float m_new = fmaxf(m_run, tmax);
+                    const float alpha = (m_new == -INFINITY) ? 1.f : expf(m_run - m_new);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int n = 0; n < NDV; n++) oacc[n] *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) pv[e] = (m_new == -INFINITY) ? 0.f : expf(pv[e] - m_new);
+                    m_run = m_new;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    l_run += pv[r];
+#pragma unroll
+                    for (int n = 0; n < NDV; n++)
+                        oacc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(lv[(4 * fg + r) * PITCH + 16 * n + fr], pv[r], oacc[n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- finish: row sum over the 4 lanes that share a query, normalise, store
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    const float denom = STABLE ? fmaxf(l_run, 1e-9f) : l_run;
+    const float inv = 1.0f / denom;
+    if (qi < p.S) {
+        T* og = (T*)p.o + ((long)b * p.S + qi) * p.ld_o + (long)h * p.d;
+#pragma unroll
+        for (int n = 0; n < NDV; n++) {
+            const int dv = 16 * n + 4 * fg;
+#pragma unroll
+            for (int e = 0; e < 4; e++) if (dv + e < p.d) og[dv + e] = from_f<T>(oacc[n][e] * inv);
+        }
+        if (p.lse && fg == 0) p.lse[((long)b * p.H + h) * p.S + qi] = STABLE ? l_run : (m_run + logf(l_run));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host dispatch (forward)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int DP>
+static int fwd_launch(const AttnP& p, int mode, hipStream_t st) {
+    constexpr int PITCH = DP + AT<T>::PAD;
+    const size_t lds = (size_t)2 * AT<T>::KT * PITCH * sizeof(T);
+    const dim3 grid((unsigned)cdiv(p.S, 64), (unsigned)(p.B * p.H));
+    if (mode == MM_ATTN_STABLEMAX) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)prefix_attn_fwd_k<T, DP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((prefix_attn_fwd_k<T, DP, true>), grid, dim3(256), lds, st, p);
+    } else {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)prefix_attn_fwd_k<T, DP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((prefix_attn_fwd_k<T, DP, false>), grid, dim3(256), lds, st, p);
+    }
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+template <typename T>
+static int fwd_dispatch(const AttnP& p, int mode, hipStream_t st) {
+    const int d = p.d;
+    if (d <= 32) return fwd_launch<T, 32>(p, mode, st);
+    if (d <= 64) return fwd_launch<T, 64>(p, mode, st);
+    if (d <= 128) return fwd_launch<T, 128>(p, mode, st);
+    if (d <= 192) return fwd_launch<T, 192>(p, mode, st);
+    if (d <= 256) return fwd_launch<T, 256>(p, mode, st);
+    if (d <= 512) return fwd_launch<T, 512>(p, mode, st);
+    MM_FAIL(MM_ERR_UNSUPPORTED, "prefix_attn: head_dim %d > 512", d);
+}
+
+static int attn_check(const char* who, const void* q, const void* k, const void* v, const float* cos_t, const float* sin_t,
+                      int64_t B, int64_t H, int64_t S, int64_t d, int64_t rot, int64_t prompt_len, int64_t ld, int mode, int dtype) {
+    MM_CHECK(q && k && v, "%s: null pointer", who);
+    MM_CHECK(B > 0 && H > 0 && S > 0 && d > 0, "%s: empty shape B=%lld H=%lld S=%lld d=%lld", who, (long long)B, (long long)H, (long long)S, (long long)d);
+    MM_CHECK(rot >= 0 && rot <= d && rot % 2 == 0, "%s: rot=%lld must be even and <= d", who, (long long)rot);
+    MM_CHECK(rot == 0 || (cos_t && sin_t), "%s: cos/sin tables required when rot > 0", who);
+    MM_CHECK(prompt_len >= 0 && prompt_len <= S, "%s: prompt_len=%lld out of range", who, (long long)prompt_len);
+    MM_CHECK(ld >= H * d, "%s: ld=%lld smaller than H*d", who, (long long)ld);
+    MM_CHECK(mode == MM_ATTN_SOFTMAX || mode == MM_ATTN_STABLEMAX, "%s: bad mode %d", who, mode);
+    MM_CHECK(dtype == MM_F32 || dtype == MM_BF16, "%s: bad dtype %d", who, dtype);
+    MM_CHECK(B * H < 65536 * 32 && S < (1 << 24), "%s: shape too large", who);
+    return MM_OK;
+}
+
+static bool attn_vec_ok(const void* a, const void* b, const void* c, int64_t ld, int64_t d, int dtype) {
+    const int esz = dtype == MM_BF16 ? 2 : 4;
+    const uintptr_t al = 4 * esz;
+    return ld % 4 == 0 && d % 4 == 0 && ((uintptr_t)a) % al == 0 && ((uintptr_t)b) % al == 0 && ((uintptr_t)c) % al == 0;
+}
+
+extern "C" int mm_prefix_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* cos_t,
+                                  const float* sin_t, int64_t B, int64_t H, int64_t S, int64_t d, int64_t rot,
+                                  int64_t prompt_len, int64_t ld_qkv, int mode, int dtype, void* stream) {
+    int rc = attn_check("prefix_attn_fwd", q, k, v, cos_t, sin_t, B, H, S, d, rot, prompt_len, ld_qkv, mode, dtype);
+    if (rc != MM_OK) return rc;
+    MM_CHECK(o, "prefix_attn_fwd: null output");
+    AttnP p{};
+    p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse; p.cos_t = cos_t; p.sin_t = sin_t;
+    p.B = (int)B; p.H = (int)H; p.S = (int)S; p.d = (int)d; p.rot = (int)rot; p.P = (int)prompt_len;
+    p.ld = ld_qkv; p.ld_o = H * d; p.scale = (float)(1.0 / sqrt((double)d));
+    p.vec_ok = attn_vec_ok(q, k, v, ld_qkv, d, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == MM_BF16 ? fwd_dispatch<bf16>(p, mode, st) : fwd_dispatch<float>(p, mode, st);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// backward.  P is recomputed from q,k and the saved row normaliser (no [S,S] tensor is stored):
+//   softmax:   p = exp(x - lse),            dS = p * (dP - delta)
+//   stablemax: p = s(x) / L,                dS = (dP - delta) / L * s'(x),  s'(x) = x<0 ? s(x)^2 : 1
+// with dP = dO.V^T and delta = rowsum(dO * O).  Two kernels, no atomics, deterministic:
+//   bwd_dq : one wave per 16 queries, streams key tiles:   dq^T += K^T . dS^T
+//   bwd_dkv: one wave per 16 keys,    streams query tiles: dk^T += Q^T . dS,  dv^T += dO^T . P
+// Every operand tile lives in LDS; transposed operands come from ds_read_b64_tr_b16 (bf16) or plain
+// strided ds_read_b32 (f32).  Gradients w.r.t. the un-rotated q,k are obtained by the inverse rotation
+// in the epilogue.
+// ------------------------------------------------------------------------------------------------
+__global__ void attn_delta_k(const void* __restrict__ o, const void* __restrict__ d_o, float* __restrict__ delta, long rows,
+                             int H, int S, int d, long ld_o, long ld_d, int is_bf16) {
+    // rows = B*S*H; 16 lanes per row; delta layout [B][H][S]
+    const int lane = threadIdx.x & 63, li = lane & 15;
+    long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = row < rows;
+    if (!live) row = rows - 1;
+    const int h = (int)(row % H);
+    const long bs = row / H;                  // b*S + s
+    float acc = 0.f;
+    for (int c = li; c < d; c += 16) {
+        float a, g;
+        if (is_bf16) { a = to_f(((const bf16*)o)[bs * ld_o + (long)h * d + c]); g = to_f(((const bf16*)d_o)[bs * ld_d + (long)h * d + c]); }
+        else { a = ((const float*)o)[bs * ld_o + (long)h * d + c]; g = ((const float*)d_o)[bs * ld_d + (long)h * d + c]; }
+        acc = fmaf(a, g, acc);
+    }
+    acc = group_sum<16>(acc);
+    if (live && li == 0) { const long b = bs / S, s = bs % S; delta[(b * H + h) * S + s] = acc; }
+}
+
+template <int DP>
+__device__ __forceinline__ void unrope_store(float* stg, int pitch, int row0, int nrows, int S, int d, int rot,
+                                             const float* __restrict__ cos_t, const float* __restrict__ sin_t, bool do_rope,
+                                             void* __restrict__ out, long ld, bool is_bf16) {
+    // stg: [nrows][pitch] f32 gradients w.r.t. ROTATED rows; apply R^T then store rows row0.. of [S][d] (stride ld)
+    const int half = rot >> 1;
+    if (do_rope) {
+        for (int idx = threadIdx.x; idx < nrows * half; idx += blockDim.x) {
+            const int r = idx / half, i = idx % half;
+            const int pos = row0 + r;
+            if (pos < S) {
+                const float c = cos_t[(long)pos * half + i], s = sin_t[(long)pos * half + i];
+                const float a = stg[r * pitch + i], b = stg[r * pitch + i + half];
+                stg[r * pitch + i] = a * c + b * s;
+                stg[r * pitch + i + half] = b * c - a * s;
+            }
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < nrows * d; idx += blockDim.x) {
+        const int r = idx / d, c = idx % d;
+        const int pos = row0 + r;
+        if (pos < S) {
+            if (is_bf16) ((bf16*)out)[(long)pos * ld + c] = __float2bfloat16(stg[r * pitch + c]);
+            else ((float*)out)[(long)pos * ld + c] = stg[r * pitch + c];
+        }
+    }
+}
+
+template <typename T, int DP, bool STABLE>
+__global__ __launch_bounds__(64) void prefix_attn_bwd_dq_k(const AttnP p) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int KT = AT<T>::KT, PITCH = DP + AT<T>::PAD, KSTEP = AT<T>::KSTEP;
+    constexpr int NKS = DP / KSTEP, NDV = DP / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* lq = reinterpret_cast<T*>(smem);
+    T* ldo = lq + 16 * PITCH;
+    T* lk = ldo + 16 * PITCH;
+    T* lv = lk + KT * PITCH;
+    const int lane = threadIdx.x, fr = lane & 15, fg = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = blockIdx.x * 16;
+    const long head_off = (long)b * p.S * p.ld + (long)h * p.d;
+    const T* qg = (const T*)p.q + head_off;
+    const T* kg = (const T*)p.k + head_off;
+    const T* vg = (const T*)p.v + head_off;
+    const T* dog = (const T*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d;
+    stage_rows<T, DP>(lq, PITCH, qg, p.ld, q0, 16, p.S, p.d, p.vec_ok);
+    stage_rows<T, DP>(ldo, PITCH, dog, p.ld_o, q0, 16, p.S, p.d, p.vec_ok);
+    __syncthreads();
+    rope_rows<T>(lq, PITCH, q0, 16, p.S, p.rot, p.cos_t, p.sin_t, false);
+    __syncthreads();
+    const int qi = q0 + fr;
+    const bool qok = qi < p.S;
+    const long stat = ((long)b * p.H + h) * p.S + (qok ? qi : 0);
+    const float lse = p.lse[stat], dlt = p.delta[stat];
+    const float invL = STABLE ? 1.0f / fmaxf(lse, 1e-9f) : 0.f;
+    int kend = min(q0 + 15, p.S - 1) + 1;
+    if (q0 < p.P) kend = max(kend, p.P);
+    kend = min(kend, p.S);
+
+    f32x4_t dqa[NDV];
+#pragma unroll
+    for (int n = 0; n < NDV; n++) dqa[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < kend; k0 += KT) {
+        stage_rows<T, DP>(lk, PITCH, kg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP>(lv, PITCH, vg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
+        __syncthreads();
+        rope_rows<T>(lk, PITCH, k0, KT, p.S, p.rot, p.cos_t, p.sin_t, false);
+        __syncthreads();
+        if constexpr (BF) {
+            f32x4_t sa[2], da[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                sa[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; da[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ks++) {
+                    const int off = ks * 32 + fg * 8;
+                    const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(&lq[fr * PITCH + off]);
+                    const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(&ldo[fr * PITCH + off]);
+                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&lk[(16 * t + fr) * PITCH + off]);
+                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(&lv[(16 * t + fr) * PITCH + off]);
+                    sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, sa[t], 0, 0, 0);
+                    da[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf, da[t], 0, 0, 0);
+                }
+            }
+            bf16x8_t dsf;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int kj = k0 + 16 * t + 4 * fg + r;
+                    const float x = sa[t][r] * p.scale;
+                    float ds = 0.f;
+                    if (qok && attn_allowed(qi, kj, p.P, p.S)) {
+                        if (STABLE) { const float s = stable_s_f(x); ds = (da[t][r] - dlt) * invL * (x < 0.f ? s * s : 1.f); }
+                        else { const float pr = __expf(x - lse); ds = pr * (da[t][r] - dlt); }
+                    }
+                    dsf[4 * t + r] = (short)f2bf(ds);
+                }
+            typedef bf16x4_t __attribute__((address_space(3))) * lds4p;
+            const int qq = fr >> 2, pp = fr & 3;
+#pragma unroll
+            for (int n = 0; n < NDV; n++) {
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lk[(4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lk[(16 + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                const bf16x8_t kt = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                dqa[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf, dqa[n], 0, 0, 0);
+            }
+        } else {
+            f32x4_t sa = f32x4_t{0.f, 0.f, 0.f, 0.f}, da = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                const int off = ks * 4 + fg;
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(lk[fr * PITCH + off], lq[fr * PITCH + off], sa, 0, 0, 0);
+                da = __builtin_amdgcn_mfma_f32_16x16x4f32(lv[fr * PITCH + off], ldo[fr * PITCH + off], da, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int kj = k0 + 4 * fg + r;
+                const float x = sa[r] * p.scale;
+                float ds = 0.f;
+                if (qok && attn_allowed(qi, kj, p.P, p.S)) {
+                    if (STABLE) { const float s = stable_s_f(x); ds = (da[r] - dlt) * invL * (x < 0.f ? s * s : 1.f); }
+                    else { const float pr = expf(x - lse); ds = pr * (da[r] - dlt); }
+                }
+#pragma unroll
+                for (int n = 0; n < NDV; n++)
+                    dqa[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(lk[(4 * fg + r) * PITCH + 16 * n + fr], ds, dqa[n], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: dq^T -> LDS [16][DP+1] f32 -> inverse rotation -> global
+    float* stg = reinterpret_cast<float*>(lk);
+    constexpr int SP = DP + 1;
+#pragma unroll
+    for (int n = 0; n < NDV; n++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) stg[fr * SP + 16 * n + 4 * fg + e] = dqa[n][e] * p.scale;
+    __syncthreads();
+    unrope_store<DP>(stg, SP, q0, 16, p.S, p.d, p.rot, p.cos_t, p.sin_t, p.rot > 0,
+                     (void*)((T*)p.dq + (long)b * p.S * p.ld_d + (long)h * p.d), p.ld_d, BF);
+}
+
+template <typename T, int DP, bool STABLE>
+__global__ __launch_bounds__(64) void prefix_attn_bwd_dkv_k(const AttnP p) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int QT = AT<T>::KT, PITCH = DP + AT<T>::PAD, KSTEP = AT<T>::KSTEP;
+    constexpr int NKS = DP / KSTEP, NDV = DP / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* lk = reinterpret_cast<T*>(smem);
+    T* lv = lk + 16 * PITCH;
+    T* lq = lv + 16 * PITCH;
+    T* ldo = lq + QT * PITCH;
+    float* lstat = reinterpret_cast<float*>(ldo + QT * PITCH);      // [2][QT]: lse, delta
+    const int lane = threadIdx.x, fr = lane & 15, fg = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int kb0 = blockIdx.x * 16;
+    const long head_off = (long)b * p.S * p.ld + (long)h * p.d;
+    const T* qg = (const T*)p.q + head_off;
+    const T* kg = (const T*)p.k + head_off;
+    const T* vg = (const T*)p.v + head_off;
+    const T* dog = (const T*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d;
+    stage_rows<T, DP>(lk, PITCH, kg, p.ld, kb0, 16, p.S, p.d, p.vec_ok);
+    stage_rows<T, DP>(lv, PITCH, vg, p.ld, kb0, 16, p.S, p.d, p.vec_ok);
+    __syncthreads();
+    rope_rows<T>(lk, PITCH, kb0, 16, p.S, p.rot, p.cos_t, p.sin_t, false);
+    __syncthreads();
+    const int kj = kb0 + fr;                         // this lane's key
+    const long statbase = ((long)b * p.H + h) * p.S;
+    // first query tile that can see any of these keys: prompt keys are seen by every query
+    const int qstart = (kb0 < p.P) ? 0 : (kb0 / QT) * QT;
+
+    f32x4_t dka[NDV], dva[NDV];
+#pragma unroll
+    for (int n = 0; n < NDV; n++) { dka[n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dva[n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int q0 = qstart; q0 < p.S; q0 += QT) {
+        stage_rows<T, DP>(lq, PITCH, qg, p.ld, q0, QT, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP>(ldo, PITCH, dog, p.ld_o, q0, QT, p.S, p.d, p.vec_ok);
+        if (lane < QT) {
+            const int qi = q0 + lane;
+            lstat[lane] = qi < p.S ? p.lse[statbase + qi] : 1.f;
+            lstat[QT + lane] = qi < p.S ? p.delta[statbase + qi] : 0.f;
+        }
+        __syncthreads();
+        rope_rows<T>(lq, PITCH, q0, QT, p.S, p.rot, p.cos_t, p.sin_t, false);
+        __syncthreads();
+        if constexpr (BF) {
+            // S[query][key]: A = Q rows, B = K rows  -> lane = key, registers = 4 queries (x2 tiles)
+            f32x4_t sa[2], da[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                sa[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; da[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ks++) {
+                    const int off = ks * 32 + fg * 8;
+                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&lk[fr * PITCH + off]);
+                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(&lv[fr * PITCH + off]);
+                    const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(&lq[(16 * t + fr) * PITCH + off]);
+                    const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(&ldo[(16 * t + fr) * PITCH + off]);
+                    sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, sa[t], 0, 0, 0);
+                    da[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf, da[t], 0, 0, 0);
+                }
+            }
+            bf16x8_t pf, dsf;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int ql = 16 * t + 4 * fg + r;
+                    const int qi = q0 + ql;
+                    const float x = sa[t][r] * p.scale;
+                    float pr = 0.f, ds = 0.f;
+                    if (qi < p.S && attn_allowed(qi, kj, p.P, p.S)) {
+                        const float lse = lstat[ql], dlt = lstat[QT + ql];
+                        if (STABLE) {
+                            const float s = stable_s_f(x), invL = 1.0f / fmaxf(lse, 1e-9f);
+                            pr = s * invL; ds = (da[t][r] - dlt) * invL * (x < 0.f ? s * s : 1.f);
+                        } else { pr = __expf(x - lse); ds = pr * (da[t][r] - dlt); }
+                    }
+                    pf[4 * t + r] = (short)f2bf(pr); dsf[4 * t + r] = (short)f2bf(ds);
+                }
+            typedef bf16x4_t __attribute__((address_space(3))) * lds4p;
+            const int qq = fr >> 2, pp = fr & 3;
+#pragma unroll
+            for (int n = 0; n < NDV; n++) {
+                const bf16x4_t glo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&ldo[(4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                const bf16x4_t ghi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&ldo[(16 + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                const bf16x8_t gt = bf16x8_t{glo[0], glo[1], glo[2], glo[3], ghi[0], ghi[1], ghi[2], ghi[3]};
+                dva[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf, dva[n], 0, 0, 0);
+                const bf16x4_t qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lq[(4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                const bf16x4_t qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lq[(16 + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                const bf16x8_t qt = bf16x8_t{qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+                dka[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf, dka[n], 0, 0, 0);
+            }
+        } else {
+            f32x4_t sa = f32x4_t{0.f, 0.f, 0.f, 0.f}, da = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                const int off = ks * 4 + fg;
+                sa = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[fr * PITCH + off], lk[fr * PITCH + off], sa, 0, 0, 0);
+                da = __builtin_amdgcn_mfma_f32_16x16x4f32(ldo[fr * PITCH + off], lv[fr * PITCH + off], da, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int ql = 4 * fg + r;
+                const int qi = q0 + ql;
+                const float x = sa[r] * p.scale;
+                float pr = 0.f, ds = 0.f;
+                if (qi < p.S && attn_allowed(qi, kj, p.P, p.S)) {
+                    const float lse = lstat[ql], dlt = lstat[QT + ql];
+                    if (STABLE) {
+                        const float s = stable_s_f(x), invL = 1.0f / fmaxf(lse, 1e-9f);
+                        pr = s * invL; ds = (da[r] - dlt) * invL * (x < 0.f ? s * s : 1.f);
+                    } else { pr = expf(x - lse); ds = pr * (da[r] - dlt); }
+                }
+#pragma unroll
+                for (int n = 0; n < NDV; n++) {
+                    dva[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ldo[ql * PITCH + 16 * n + fr], pr, dva[n], 0, 0, 0);
+                    dka[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(lq[ql * PITCH + 16 * n + fr], ds, dka[n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue through LDS (f32 [16][DP+1]); the Q/dO tile region is free now
+    float* stg = reinterpret_cast<float*>(lq);
+    constexpr int SP = DP + 1;
+#pragma unroll
+    for (int n = 0; n < NDV; n++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) stg[fr * SP + 16 * n + 4 * fg + e] = dva[n][e];
+    __syncthreads();
+    unrope_store<DP>(stg, SP, kb0, 16, p.S, p.d, 0, p.cos_t, p.sin_t, false,
+                     (void*)((T*)p.dv + (long)b * p.S * p.ld_d + (long)h * p.d), p.ld_d, BF);
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NDV; n++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) stg[fr * SP + 16 * n + 4 * fg + e] = dka[n][e] * p.scale;
+    __syncthreads();
+    unrope_store<DP>(stg, SP, kb0, 16, p.S, p.d, p.rot, p.cos_t, p.sin_t, p.rot > 0,
+                     (void*)((T*)p.dk + (long)b * p.S * p.ld_d + (long)h * p.d), p.ld_d, BF);
+}
+
+template <typename T, int DP>
+static int bwd_launch(const AttnP& p, int mode, hipStream_t st) {
+    constexpr int PITCH = DP + AT<T>::PAD, KT = AT<T>::KT;
+    const size_t lds_q = (size_t)(32 + 2 * KT) * PITCH * sizeof(T);
+    size_t lds_kv = (size_t)(32 + 2 * KT) * PITCH * sizeof(T) + 2 * KT * sizeof(float);
+    // the f32 epilogue staging tile [16][DP+1] must fit in the streamed-tile region
+    const size_t need = (size_t)16 * (DP + 1) * sizeof(float);
+    static_assert((size_t)2 * AT<T>::KT * (DP + AT<T>::PAD) * sizeof(T) >= (size_t)16 * (DP + 1) * sizeof(float), "staging tile does not fit");
+    (void)need;
+    const dim3 gq((unsigned)cdiv(p.S, 16), (unsigned)(p.B * p.H));
+#define SETATTR_(K_, BYTES_) if ((BYTES_) > 64 * 1024) (void)hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES_))
+    if (mode == MM_ATTN_STABLEMAX) {
+        SETATTR_((prefix_attn_bwd_dq_k<T, DP, true>), lds_q);
+        hipLaunchKernelGGL((prefix_attn_bwd_dq_k<T, DP, true>), gq, dim3(64), lds_q, st, p);
+        SETATTR_((prefix_attn_bwd_dkv_k<T, DP, true>), lds_kv);
+        hipLaunchKernelGGL((prefix_attn_bwd_dkv_k<T, DP, true>), gq, dim3(64), lds_kv, st, p);
+    } else {
+        SETATTR_((prefix_attn_bwd_dq_k<T, DP, false>), lds_q);
+        hipLaunchKernelGGL((prefix_attn_bwd_dq_k<T, DP, false>), gq, dim3(64), lds_q, st, p);
+        SETATTR_((prefix_attn_bwd_dkv_k<T, DP, false>), lds_kv);
+        hipLaunchKernelGGL((prefix_attn_bwd_dkv_k<T, DP, false>), gq, dim3(64), lds_kv, st, p);
+    }
+#undef SETATTR_
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+template <typename T>
+static int bwd_dispatch(const AttnP& p, int mode, hipStream_t st) {
+    const int d = p.d;
+    if (d <= 32) return bwd_launch<T, 32>(p, mode, st);
+    if (d <= 64) return bwd_launch<T, 64>(p, mode, st);
+    if (d <= 128) return bwd_launch<T, 128>(p, mode, st);
+    if (d <= 192) return bwd_launch<T, 192>(p, mode, st);
+    if (d <= 256) return bwd_launch<T, 256>(p, mode, st);
+    if (d <= 512) return bwd_launch<T, 512>(p, mode, st);
+    MM_FAIL(MM_ERR_UNSUPPORTED, "prefix_attn_bwd: head_dim %d > 512", d);
+}
+
+extern "C" size_t mm_prefix_attn_bwd_workspace(int64_t B, int64_t H, int64_t S) {
+    return (B > 0 && H > 0 && S > 0) ? (size_t)(B * H * S) * sizeof(float) : 0;
+}
+
+extern "C" int mm_prefix_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                                  void* dq, void* dk, void* dv, const float* cos_t, const float* sin_t, void* workspace,
+                                  size_t workspace_bytes, int64_t B, int64_t H, int64_t S, int64_t d, int64_t rot,
+                                  int64_t prompt_len, int64_t ld_qkv, int64_t ld_dqkv, int mode, int dtype, void* stream) {
+    int rc = attn_check("prefix_attn_bwd", q, k, v, cos_t, sin_t, B, H, S, d, rot, prompt_len, ld_qkv, mode, dtype);
+    if (rc != MM_OK) return rc;
+    MM_CHECK(o && d_o && lse && dq && dk && dv && workspace, "prefix_attn_bwd: null pointer");
+    MM_CHECK(ld_dqkv >= H * d, "prefix_attn_bwd: ld_dqkv too small");
+    MM_CHECK(workspace_bytes >= mm_prefix_attn_bwd_workspace(B, H, S), "prefix_attn_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    AttnP p{};
+    p.q = q; p.k = k; p.v = v; p.o = (void*)o; p.lse = (float*)lse; p.dO = d_o; p.dq = dq; p.dk = dk; p.dv = dv;
+    p.delta = (const float*)workspace; p.cos_t = cos_t; p.sin_t = sin_t;
+    p.B = (int)B; p.H = (int)H; p.S = (int)S; p.d = (int)d; p.rot = (int)rot; p.P = (int)prompt_len;
+    p.ld = ld_qkv; p.ld_o = H * d; p.ld_d = ld_dqkv; p.scale = (float)(1.0 / sqrt((double)d));
+    p.vec_ok = attn_vec_ok(q, k, v, ld_qkv, d, dtype) && attn_vec_ok(d_o, d_o, d_o, H * d, d, dtype);
+    const long rows = B * S * H;
+    hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, o, d_o, (float*)workspace, rows, (int)H, (int)S,
+                       (int)d, (long)(H * d), (long)(H * d), dtype == MM_BF16 ? 1 : 0);
+    MM_LAUNCH_CHECK();
+    return dtype == MM_BF16 ? bwd_dispatch<bf16>(p, mode, st) : bwd_dispatch<float>(p, mode, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: decode step against the KV cache.  One wave per (b,h).  16 lanes cover one cache row (coalesced
+// 16-byte loads), 4 keys per wave instruction; scores go through LDS, so K and V are each read once.
+// HBM-bound: algorithmic bytes = 2 * (pos+1) * d * sizeof(T) per (b,h).
+// ------------------------------------------------------------------------------------------------
+struct DecP {
+    const void* q; const void* kn; const void* vn; void* kc; void* vc; void* o;
+    const float* cos_t; const float* sin_t;
+    int B, H, d, rot, pos, Smax; long ld; float scale; int mode;
+};
+
+template <typename T, int VEC, int CH>
+__global__ __launch_bounds__(256) void decode_attn_k(const DecP p) {
+    constexpr int SC_MAX = 1024;
+    __shared__ float sc[4][SC_MAX];
+    __shared__ float rq[4][512], rk[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, grp = lane >> 4;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= p.B * p.H) return;                       // wave-uniform
+    const int b = bh / p.H, h = bh % p.H;
+    const int d = p.d, half = p.rot >> 1, pos = p.pos;
+    const T* qg = (const T*)p.q + (long)b * p.ld + (long)h * d;
+    const T* kng = (const T*)p.kn + (long)b * p.ld + (long)h * d;
+    const T* vng = (const T*)p.vn + (long)b * p.ld + (long)h * d;
+    T* kc = (T*)p.kc + (long)bh * p.Smax * d;
+    T* vc = (T*)p.vc + (long)bh * p.Smax * d;
+    // ---- rotate q and k_new at position pos (through LDS: the partner element lives in another lane)
+    for (int c = lane; c < d; c += 64) { rq[wave][c] = to_f(qg[c]); rk[wave][c] = to_f(kng[c]); }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): own LDS writes landed (single wave owns its rows)
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < half; i += 64) {
+        const float c = p.cos_t[(long)pos * half + i], s = p.sin_t[(long)pos * half + i];
+        const float a = rq[wave][i], bb = rq[wave][i + half];
+        rq[wave][i] = a * c - bb * s; rq[wave][i + half] = bb * c + a * s;
+        const float a2 = rk[wave][i], b2 = rk[wave][i + half];
+        rk[wave][i] = a2 * c - b2 * s; rk[wave][i + half] = b2 * c + a2 * s;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    // registers: this lane's slice of q (rounded to T like the prefill kernel does), k_new, v_new
+    float qv[CH][VEC], knv[CH][VEC], vnv[CH][VEC];
+    bool cok[CH];
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int c = (k * 16 + li) * VEC;
+        cok[k] = c < d;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            const bool ok = c + v < d;
+            qv[k][v] = ok ? to_f(from_f<T>(rq[wave][c + v])) : 0.f;
+            knv[k][v] = ok ? to_f(from_f<T>(rk[wave][c + v])) : 0.f;
+            vnv[k][v] = ok ? to_f(vng[c + v]) : 0.f;
+        }
+    }
+    // append to the cache (group 0 writes)
+    if (grp == 0) {
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+            if (cok[k]) {
+                const int c = (k * 16 + li) * VEC;
+                VecIO<T, VEC>::store(kc + (long)pos * d + c, knv[k]);
+                VecIO<T, VEC>::store(vc + (long)pos * d + c, vnv[k]);
+            }
+    }
+    // ---- pass 1: scores of cached keys 0..pos-1 (4 per iteration), the new key from registers
+    float mx = -INFINITY;
+    for (int j0 = 0; j0 < pos; j0 += 4) {
+        const int j = j0 + grp;
+        float dot = 0.f;
+        if (j < pos) {
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+                if (cok[k]) {
+                    float kv[VEC];
+                    VecIO<T, VEC>::load(kc + (long)j * d + (k * 16 + li) * VEC, kv);
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) dot = fmaf(qv[k][v], kv[v], dot);
+                }
+        }
+        dot = group_sum<16>(dot) * p.scale;
+        if (j < pos) { if (li == 0) sc[wave][j] = dot; mx = fmaxf(mx, dot); }
+    }
+    float dn = 0.f;
+#pragma unroll
+    for (int k = 0; k < CH; k++)
+#pragma unroll
+        for (int v = 0; v < VEC; v++) dn = fmaf(qv[k][v], knv[k][v], dn);
+    dn = group_sum<16>(dn) * p.scale;                   // every group computes the same value
+    mx = fmaxf(mx, dn);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    // ---- pass 2: weights and P.V
+    const bool stable = p.mode == MM_ATTN_STABLEMAX;
+    float oacc[CH][VEC];
+    float lsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < CH; k++)
+#pragma unroll
+        for (int v = 0; v < VEC; v++) oacc[k][v] = 0.f;
+    for (int j0 = 0; j0 < pos; j0 += 4) {
+        const int j = j0 + grp;
+        if (j < pos) {
+            const float x = sc[wave][j];
+            const float w = stable ? stable_s_f(x) : __expf(x - mx);
+            lsum += w;
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+                if (cok[k]) {
+                    float vv[VEC];
+                    VecIO<T, VEC>::load(vc + (long)j * d + (k * 16 + li) * VEC, vv);
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) oacc[k][v] = fmaf(w, vv[v], oacc[k][v]);
+                }
+        }
+    }
+    if (grp == 0) {                                      // the new token's own key/value
+        const float w = stable ? stable_s_f(dn) : __expf(dn - mx);
+        lsum += w;
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+#pragma unroll
+            for (int v = 0; v < VEC; v++) oacc[k][v] = fmaf(w, vnv[k][v], oacc[k][v]);
+    }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    const float inv = 1.0f / (stable ? fmaxf(lsum, 1e-9f) : lsum);
+    T* og = (T*)p.o + (long)b * p.H * d + (long)h * d;
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        float r[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            float t = oacc[k][v];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            r[v] = t * inv;
+        }
+        if (grp == 0 && cok[k]) VecIO<T, VEC>::store(og + (k * 16 + li) * VEC, r);
+    }
+}
+
+template <typename T>
+__global__ void kv_cache_fill_k(const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ kc, T* __restrict__ vc,
+                                const float* __restrict__ cos_t, const float* __restrict__ sin_t, int B, int H, int S, int d,
+                                int rot, int Smax, long ld) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * S * H * d;
+    if (idx >= total) return;
+    const int c = (int)(idx % d);
+    const int h = (int)((idx / d) % H);
+    const int s = (int)((idx / ((long)d * H)) % S);
+    const int b = (int)(idx / ((long)d * H * S));
+    const long src = ((long)b * S + s) * ld + (long)h * d;
+    const long dst = (((long)b * H + h) * Smax + s) * d + c;
+    const int half = rot >> 1;
+    float kv = to_f(k[src + c]);
+    if (c < rot) {
+        const int i = c < half ? c : c - half;
+        const float cs = cos_t[(long)s * half + i], sn = sin_t[(long)s * half + i];
+        const float other = to_f(k[src + (c < half ? c + half : c - half)]);
+        kv = c < half ? kv * cs - other * sn : kv * cs + other * sn;
+    }
+    kc[dst] = from_f<T>(kv);
+    vc[dst] = v[src + c];
+}
+
+extern "C" int mm_kv_cache_fill(const void* k, const void* v, void* kcache, void* vcache, const float* cos_t,
+                                const float* sin_t, int64_t B, int64_t H, int64_t S, int64_t d, int64_t rot, int64_t Smax,
+                                int64_t ld_qkv, int dtype, void* stream) {
+    MM_CHECK(k && v && kcache && vcache, "kv_cache_fill: null pointer");
+    MM_CHECK(B > 0 && H > 0 && S > 0 && d > 0 && S <= Smax, "kv_cache_fill: bad shape (S=%lld Smax=%lld)", (long long)S, (long long)Smax);
+    MM_CHECK(rot >= 0 && rot <= d && rot % 2 == 0 && (rot == 0 || (cos_t && sin_t)), "kv_cache_fill: bad rot/tables");
+    MM_CHECK(ld_qkv >= H * d, "kv_cache_fill: ld too small");
+    const long total = B * S * H * d;
+    const dim3 grid((unsigned)cdiv(total, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MM_BF16) hipLaunchKernelGGL(kv_cache_fill_k<bf16>, grid, dim3(256), 0, st, (const bf16*)k, (const bf16*)v, (bf16*)kcache, (bf16*)vcache, cos_t, sin_t, (int)B, (int)H, (int)S, (int)d, (int)rot, (int)Smax, (long)ld_qkv);
+    else if (dtype == MM_F32) hipLaunchKernelGGL(kv_cache_fill_k<float>, grid, dim3(256), 0, st, (const float*)k, (const float*)v, (float*)kcache, (float*)vcache, cos_t, sin_t, (int)B, (int)H, (int)S, (int)d, (int)rot, (int)Smax, (long)ld_qkv);
+    else MM_FAIL(MM_ERR_ARG, "kv_cache_fill: bad dtype %d", dtype);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+extern "C" int mm_decode_attn(const void* q, const void* k_new, const void* v_new, void* kcache, void* vcache, void* o,
+                              const float* cos_t, const float* sin_t, int64_t B, int64_t H, int64_t d, int64_t rot,
+                              int64_t pos, int64_t Smax, int64_t ld_qkv, int mode, int dtype, void* stream) {
+    MM_CHECK(q && k_new && v_new && kcache && vcache && o, "decode_attn: null pointer");
+    MM_CHECK(B > 0 && H > 0 && d > 0 && d <= 512, "decode_attn: bad shape (d=%lld, max 512)", (long long)d);
+    MM_CHECK(pos >= 0 && pos < Smax && Smax <= 1024, "decode_attn: pos=%lld Smax=%lld (Smax <= 1024)", (long long)pos, (long long)Smax);
+    MM_CHECK(rot >= 0 && rot <= d && rot % 2 == 0 && (rot == 0 || (cos_t && sin_t)), "decode_attn: bad rot/tables");
+    MM_CHECK(ld_qkv >= H * d, "decode_attn: ld too small");
+    MM_CHECK(mode == MM_ATTN_SOFTMAX || mode == MM_ATTN_STABLEMAX, "decode_attn: bad mode %d", mode);
+    DecP p{};
+    p.q = q; p.kn = k_new; p.vn = v_new; p.kc = kcache; p.vc = vcache; p.o = o; p.cos_t = cos_t; p.sin_t = sin_t;
+    p.B = (int)B; p.H = (int)H; p.d = (int)d; p.rot = (int)rot; p.pos = (int)pos; p.Smax = (int)Smax; p.ld = ld_qkv;
+    p.scale = (float)(1.0 / sqrt((double)d)); p.mode = mode;
+    const dim3 grid((unsigned)cdiv(B * H, 4));
+    hipStream_t st = (hipStream_t)stream;
+    // vector width: the cache rows are d elements apart, so VEC must divide d
+#define L_(T_, VEC_, CH_) hipLaunchKernelGGL((decode_attn_k<T_, VEC_, CH_>), grid, dim3(256), 0, st, p)
+    if (dtype == MM_BF16) {
+        const bool a16 = ((uintptr_t)kcache % 16 == 0) && ((uintptr_t)vcache % 16 == 0) && ((uintptr_t)o % 16 == 0);
+        if (d % 8 == 0 && a16) { if (d <= 128) L_(bf16, 8, 1); else if (d <= 256) L_(bf16, 8, 2); else L_(bf16, 8, 4); }
+        else if (d % 4 == 0) { if (d <= 64) L_(bf16, 4, 1); else if (d <= 128) L_(bf16, 4, 2); else if (d <= 256) L_(bf16, 4, 4); else L_(bf16, 4, 8); }
+        else MM_FAIL(MM_ERR_UNSUPPORTED, "decode_attn: head_dim %lld must be a multiple of 4", (long long)d);
+    } else if (dtype == MM_F32) {
+        if (d % 4 == 0) { if (d <= 64) L_(float, 4, 1); else if (d <= 128) L_(float, 4, 2); else if (d <= 256) L_(float, 4, 4); else L_(float, 4, 8); }
+        else MM_FAIL(MM_ERR_UNSUPPORTED, "decode_attn: head_dim %lld must be a multiple of 4", (long long)d);
+    } else MM_FAIL(MM_ERR_ARG, "decode_attn: bad dtype %d", dtype);
+#undef L_
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}

@@ -220,3 +220,84 @@ def colsum(x: Tensor, M: int, N: int) -> Tensor:
     L.check(L.lib().mm_colsum(L.ptr(x2), L.ptr(out), L.ptr(ws), nbytes, M, N, x2.stride(0), L.dtype_code(x), L.cur_stream()),
             "mm_colsum")
     return out
+
+
+# --------------------------------------------------------------------------- attention
+_rope_cache = {}
+
+
+def rope_tables(inv_freq: Tensor, seq_len: int):
+    """cos/sin [S, rot/2] f32, computed as the reference does (transformer_decoder.py:18-22); the second half of
+    the reference's table repeats the first (emb = cat(freqs, freqs)), so only rot/2 columns are kept."""
+    key = (inv_freq.data_ptr(), inv_freq.device, seq_len, inv_freq._version)
+    hit = _rope_cache.get(key)
+    if hit is None:
+        t = torch.arange(seq_len, device=inv_freq.device)
+        freqs = torch.einsum("i,j->ij", t, inv_freq.float())
+        hit = (freqs.cos().contiguous(), freqs.sin().contiguous())
+        if len(_rope_cache) > 64:
+            _rope_cache.clear()
+        _rope_cache[key] = hit
+    return hit
+
+
+def _qkv_geom(q: Tensor, k: Tensor, v: Tensor, H: int):
+    """q,k,v: [B,S,E] views with unit inner stride and a common row stride (e.g. slices of one [B,S,3E] tensor)."""
+    B, S, E = q.shape
+    for t in (q, k, v):
+        if not t.is_cuda or t.shape != q.shape or t.dtype != q.dtype or t.stride(2) != 1 or t.stride(1) != q.stride(1) \
+                or (B > 1 and t.stride(0) != S * q.stride(1)):
+            raise RuntimeError("attention: q,k,v must be GPU [B,S,E] views with unit inner stride and equal row strides")
+    if E % H:
+        raise RuntimeError("attention: E not divisible by H")
+    return B, S, E, E // H, q.stride(1)
+
+
+def prefix_attn_fwd(q: Tensor, k: Tensor, v: Tensor, H: int, rot: int, prompt_len: int, cos_t: Tensor, sin_t: Tensor,
+                    stablemax: bool, save_lse: bool = False):
+    B, S, E, d, ld = _qkv_geom(q, k, v, H)
+    o = torch.empty((B, S, E), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device) if save_lse else None
+    L.check(L.lib().mm_prefix_attn_fwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(cos_t), L.ptr(sin_t),
+                                       B, H, S, d, rot, prompt_len, ld, int(stablemax), L.dtype_code(q), L.cur_stream()),
+            "mm_prefix_attn_fwd")
+    return o, lse
+
+
+def prefix_attn_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, d_o: Tensor, lse: Tensor, H: int, rot: int,
+                    prompt_len: int, cos_t: Tensor, sin_t: Tensor, stablemax: bool):
+    """Returns dqkv [B,S,3,E] (so dq,dk,dv are views with row stride 3E, ready for a fused QKV weight gradient)."""
+    B, S, E, d, ld = _qkv_geom(q, k, v, H)
+    _chk(o, "o", q.dtype); _chk(d_o, "dO", q.dtype)
+    dqkv = torch.empty((B, S, 3, E), dtype=q.dtype, device=q.device)
+    nbytes = L.lib().mm_prefix_attn_bwd_workspace(B, H, S)
+    ws = workspace(nbytes, q.device, "attn")
+    L.check(L.lib().mm_prefix_attn_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(d_o), L.ptr(lse),
+                                       dqkv.data_ptr(), dqkv.data_ptr() + E * dqkv.element_size(),
+                                       dqkv.data_ptr() + 2 * E * dqkv.element_size(), L.ptr(cos_t), L.ptr(sin_t), L.ptr(ws),
+                                       nbytes, B, H, S, d, rot, prompt_len, ld, 3 * E, int(stablemax), L.dtype_code(q),
+                                       L.cur_stream()), "mm_prefix_attn_bwd")
+    return dqkv
+
+
+def kv_cache_fill(k: Tensor, v: Tensor, kcache: Tensor, vcache: Tensor, H: int, rot: int, cos_t: Tensor, sin_t: Tensor):
+    B, S, E = k.shape
+    d = E // H
+    Smax = kcache.shape[2]
+    for t in (k, v):
+        if t.stride(2) != 1 or t.stride(1) != k.stride(1) or (B > 1 and t.stride(0) != S * k.stride(1)):
+            raise RuntimeError("kv_cache_fill: k,v must be [B,S,E] views whose batch stride is S * row stride")
+    L.check(L.lib().mm_kv_cache_fill(L.ptr(k), L.ptr(v), L.ptr(kcache), L.ptr(vcache), L.ptr(cos_t), L.ptr(sin_t), B, H, S, d,
+                                     rot, Smax, k.stride(1), L.dtype_code(k), L.cur_stream()), "mm_kv_cache_fill")
+
+
+def decode_attn(q: Tensor, k_new: Tensor, v_new: Tensor, kcache: Tensor, vcache: Tensor, H: int, rot: int, pos: int,
+                cos_t: Tensor, sin_t: Tensor, stablemax: bool) -> Tensor:
+    """q,k_new,v_new: [B,E] views (row stride ld); caches [B,H,Smax,d]; returns o [B,E]."""
+    B, E = q.shape
+    d = E // H
+    o = torch.empty((B, E), dtype=q.dtype, device=q.device)
+    L.check(L.lib().mm_decode_attn(L.ptr(q), L.ptr(k_new), L.ptr(v_new), L.ptr(kcache), L.ptr(vcache), L.ptr(o), L.ptr(cos_t),
+                                   L.ptr(sin_t), B, H, d, rot, pos, kcache.shape[2], q.stride(0), int(stablemax),
+                                   L.dtype_code(q), L.cur_stream()), "mm_decode_attn")
+    return o
