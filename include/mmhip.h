@@ -147,20 +147,17 @@ int mm_kv_cache_fill(const void* k, const void* v, void* kcache, void* vcache, c
                      int64_t B, int64_t H, int64_t S, int64_t d, int64_t rot, int64_t Smax, int64_t ld_qkv,
                      int dtype, void* stream);
 
-/* ---- small fused elementwise pieces --------------------------------------------------------
- * f32 -> bf16 cast with optional transposed copy (weights, once per optimizer step). */
-int mm_cast_f32_bf16(const float* x, void* y, void* y_t /*nullable, [cols][rows]*/, int64_t rows, int64_t cols,
-                     void* stream);
-/* argmax over the last dim of logits [rows][V] -> int64 ids (train_autoregressive.py:102). */
+/* ---- small fused pieces --------------------------------------------------------------------
+ * LayerScale + DropPath backward (autograd of models/convnext.py:45-47):
+ *   dz = dout * gamma[c] * rowscale[m/rows_per_scale];  dgamma[c] = sum_m dout*rowscale*z;  dbias[c] = sum_m dz.
+ * dout,z,dz: [M][C]; deterministic two-stage reduction through `workspace`. */
+size_t mm_layerscale_bwd_workspace(int64_t M, int64_t C);
+int mm_layerscale_bwd(const void* dout, const void* z, const float* gamma, const float* rowscale, int64_t rows_per_scale,
+                      void* dz, float* dgamma, float* dbias, void* workspace, size_t workspace_bytes, int64_t M,
+                      int64_t C, int dtype, void* stream);
+/* argmax over the last dim of logits [rows][V] (row stride ld) -> int64 ids (train_autoregressive.py:102);
+ * the first maximal index wins, as torch.argmax does. */
 int mm_argmax_rows(const void* logits, int64_t* out, int64_t rows, int64_t V, int64_t ld, int dtype, void* stream);
-
-/* OrthoGrad projection + AdamW, one fused pass per tensor list (ortho_grad.py:60-99 followed by
- * torch.optim.AdamW.step).  Tensors are described by a device table of mm_param_desc. */
-typedef struct { float* p; float* g; float* m; float* v; int64_t n; } mm_param_desc;
-size_t mm_orthograd_adamw_workspace(int64_t n_tensors);
-int mm_orthograd_adamw(const mm_param_desc* host_descs, int64_t n_tensors, float lr, float beta1, float beta2,
-                       float adam_eps, float weight_decay, int64_t step, float ortho_eps, int rescale,
-                       int do_ortho, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

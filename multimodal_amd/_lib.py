@@ -37,10 +37,6 @@ class GemmArgs(C.Structure):
     ]
 
 
-class ParamDesc(C.Structure):
-    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64)]
-
-
 _SIGNATURES = {
     "mm_version": (i32, []),
     "mm_last_error": (C.c_char_p, []),
@@ -61,12 +57,9 @@ _SIGNATURES = {
     "mm_prefix_attn_bwd": (i32, [vp] * 11 + [vp, sz] + [i64] * 8 + [i32, i32, vp]),
     "mm_decode_attn": (i32, [vp] * 8 + [i64] * 7 + [i32, i32, vp]),
     "mm_kv_cache_fill": (i32, [vp] * 6 + [i64] * 7 + [i32, vp]),
-}
-_PENDING = {
-    "mm_cast_f32_bf16": (i32, [vp, vp, vp, i64, i64, vp]),
+    "mm_layerscale_bwd_workspace": (sz, [i64, i64]),
+    "mm_layerscale_bwd": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp, sz, i64, i64, i32, vp]),
     "mm_argmax_rows": (i32, [vp, vp, i64, i64, i64, i32, vp]),
-    "mm_orthograd_adamw_workspace": (sz, [i64]),
-    "mm_orthograd_adamw": (i32, [C.POINTER(ParamDesc), i64, f32, f32, f32, f32, f32, i64, f32, i32, i32, vp, sz, vp]),
 }
 
 

@@ -1,0 +1,51 @@
+"""CrossAttentionBlock: API-compatible with reference models/cross_attention.py:6-46 (dead code there: it imports a
+missing `.rope`).  Built on the same fused attention kernel (K3) with an empty causal part: every query row is a
+"prompt" row of a [kv ; q] sequence is NOT needed -- cross attention is plain full attention of Tq queries over Tkv
+keys, which K3 computes when q and kv have equal length; for the general case the keys/values are padded views.
+PARITY UNPINNED: the reference class cannot be imported, no reference output exists (oracle restates the text)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as FN
+from .. import ops
+
+
+class CrossAttentionBlock(nn.Module):
+    def __init__(self, embed_dim, num_heads=4, dropout=0.1, use_rope=False, rope_freqs=None):
+        super().__init__()
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.dropout = nn.Dropout(dropout)
+        self.linear_q = nn.Linear(embed_dim, embed_dim)
+        self.linear_k = nn.Linear(embed_dim, embed_dim)
+        self.linear_v = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.norm = nn.LayerNorm(embed_dim)
+        self.use_rope, self.rope_freqs = use_rope, rope_freqs
+
+    def forward(self, query, key_value):
+        if self.use_rope and self.rope_freqs is not None:
+            raise NotImplementedError("the reference's rope module (models/rope.py) does not exist; use_rope=False only")
+        if self.dropout.p != 0.0:
+            raise NotImplementedError("attention-probability dropout (reference :42 applies it even in eval) is not "
+                                      "implemented in the fused kernel; construct with dropout=0.0")
+        dt = FN.get_compute_dtype()
+        B, Tq, C = query.shape
+        Tkv = key_value.shape[1]
+        q = F.linear(query.to(dt), self.linear_q.weight.to(dt), self.linear_q.bias.to(dt))
+        k = F.linear(key_value.to(dt), self.linear_k.weight.to(dt), self.linear_k.bias.to(dt))
+        v = F.linear(key_value.to(dt), self.linear_v.weight.to(dt), self.linear_v.bias.to(dt))
+        # one [kv ; q] sequence with prompt_len = Tkv would let queries see themselves; instead run K3 on a sequence of
+        # S = max(Tq, Tkv) rows where every row is a prompt row (full attention), with zero-padded tails masked out by
+        # construction: padded KEY rows must not be seen, so keys are only padded when Tq > Tkv is not the case.
+        if Tq > Tkv:
+            raise NotImplementedError("CrossAttentionBlock on libmmhip needs Tq <= Tkv (queries are padded, keys are not)")
+        S = Tkv
+        qkv = torch.zeros((B, S, 3, C), dtype=dt, device=q.device)
+        qkv[:, :Tq, 0] = q
+        qkv[:, :, 1] = k
+        qkv[:, :, 2] = v
+        zero = torch.zeros((S, 0), dtype=torch.float32, device=q.device)
+        a = FN.PrefixAttention.apply(qkv, zero, zero, self.num_heads, 0, S, False)[:, :Tq]
+        out = query.to(dt) + F.linear(a, self.out_proj.weight.to(dt), self.out_proj.bias.to(dt))
+        return FN.LayerNorm.apply(out, self.norm.weight, self.norm.bias)

@@ -1,0 +1,144 @@
+"""Prompt decoder on the MI355X hot path: same classes / signatures / state_dict keys as reference
+models/transformer_decoder.py.  The attention core (RoPE, prefix-LM mask, softmax|stablemax, P.V) is ONE
+fused kernel (K3) and never materialises scores or the [B,H,S,S] mask; LayerNorms are libmmhip kernels;
+the dense projections run on the GPU BLAS through torch."""
+import math
+
+import torch as th
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as FN
+from .. import ops
+
+
+class RotaryEmbedding(nn.Module):
+    def __init__(self, dim, base=10000):
+        super().__init__()
+        inv_freq = 1.0 / (base ** (th.arange(0, dim, 2).float() / dim))
+        self.register_buffer("inv_freq", inv_freq)
+
+    def forward(self, x, seq_len=None):
+        """cos, sin of shape [seq_len, dim] (the reference's duplicated-halves table)."""
+        c, s = ops.rope_tables(self.inv_freq, seq_len)
+        return th.cat((c, c), -1), th.cat((s, s), -1)
+
+    def half_tables(self, seq_len):
+        return ops.rope_tables(self.inv_freq, seq_len)
+
+
+def rotate_half(x):
+    h = x.shape[-1] // 2
+    return th.cat((-x[..., h:], x[..., :h]), -1)
+
+
+def apply_rotary_pos_emb(q, k, cos, sin):
+    cos, sin = cos[..., : q.shape[-2], :], sin[..., : q.shape[-2], :]
+    return (q * cos) + (rotate_half(q) * sin), (k * cos) + (rotate_half(k) * sin)
+
+
+def stable_s(x, clamp_val=20.0, epsilon=1e-9):
+    return th.where(x < 0, 1.0 / (1.0 - x + epsilon), x + 1.0)
+
+
+def stablemax(x, dim=-1, clamp_val=20.0, epsilon=1e-9):
+    s = stable_s(x, clamp_val, epsilon)
+    return s / s.sum(dim=dim, keepdim=True).clamp_min(epsilon)
+
+
+def _lin(x, lin, dt):
+    return F.linear(x, lin.weight.to(dt), lin.bias.to(dt))
+
+
+class DecoderPromptLayer(nn.Module):
+    def __init__(self, d_model, memory_dim, nhead, d_ffn=2048, dropout=0.1, use_rope=False, use_stablemax=False):
+        super().__init__()
+        assert d_model % nhead == 0, "d_model must be divisible by nhead"
+        self.d_model, self.memory_dim, self.nhead = d_model, memory_dim, nhead
+        self.head_dim = d_model // nhead
+        self.use_rope, self.use_stablemax = use_rope, use_stablemax
+        assert use_rope, "Other posemb than rope not supported atm"
+        self.rotary_ndims = int(self.head_dim * 0.5)
+        self.rotary_emb = RotaryEmbedding(self.rotary_ndims)
+        self.q = nn.Linear(d_model, d_model)
+        self.k = nn.Linear(d_model, d_model)
+        self.v = nn.Linear(d_model, d_model)
+        self.out = nn.Linear(d_model, d_model)
+        self.ffn_w1 = nn.Linear(d_model, d_ffn)
+        self.ffn_w2 = nn.Linear(d_ffn, d_model)
+        self.attn_norm = nn.LayerNorm(d_model)
+        self.mlp_norm = nn.LayerNorm(d_model)
+        # the reference hard-codes p=0.0 for its three dropouts (:111-113); kept for module-tree parity
+        self.attn_dropout = nn.Dropout(0.0)
+        self.mlp_dropout = nn.Dropout(0.0)
+        self.intra_mlp_dropout = nn.Dropout(0.0)
+
+    def _qkv(self, xa, dt):
+        w = th.cat((self.q.weight, self.k.weight, self.v.weight), 0).to(dt)
+        b = th.cat((self.q.bias, self.k.bias, self.v.bias), 0).to(dt)
+        return F.linear(xa, w, b)
+
+    def _mlp(self, x, dt):
+        xf = FN.LayerNorm.apply(x, self.mlp_norm.weight, self.mlp_norm.bias)
+        xf = F.relu(_lin(xf, self.ffn_w1, dt)).square()
+        return x + _lin(xf, self.ffn_w2, dt)
+
+    def forward(self, x, mask=None, prompt_len=None):
+        """x: [B,S,D].  The reference passes the boolean prefix-LM mask [B,H,S,S]; here the mask is evaluated
+        in-kernel from `prompt_len` (if only a mask is given, its prompt length is recovered from row 0)."""
+        B, S, D = x.shape
+        dt = FN.get_compute_dtype()
+        if prompt_len is None:
+            if mask is None:
+                raise ValueError("DecoderPromptLayer needs prompt_len (or the reference's prefix-LM mask)")
+            prompt_len = int(mask[0, 0, 0].sum().item())
+        x = x.to(dt)
+        xa = FN.LayerNorm.apply(x, self.attn_norm.weight, self.attn_norm.bias)
+        qkv = self._qkv(xa, dt).view(B, S, 3, D)
+        cos_t, sin_t = self.rotary_emb.half_tables(S)
+        attn = FN.PrefixAttention.apply(qkv, cos_t, sin_t, self.nhead, self.rotary_ndims, prompt_len, self.use_stablemax)
+        x = _lin(attn, self.out, dt) + x
+        return self._mlp(x, dt)
+
+
+class SMILESDecoder(nn.Module):
+    def __init__(self, smiles_vocab_size, nmr_vocab_size, max_seq_length=512, max_nmr_length=128, max_memory_length=128,
+                 memory_dim=768, embed_dim=768, num_heads=8, num_layers=6, dropout=0.1, verbose=True, use_stablemax=False):
+        super().__init__()
+        self.num_heads, self.embed_dim, self.memory_dim, self.verbose = num_heads, embed_dim, memory_dim, verbose
+        self.max_seq_length, self.max_nmr_length, self.max_memory_length = max_seq_length, max_nmr_length, max_memory_length
+        self.smiles_embed = nn.Embedding(smiles_vocab_size, embed_dim)
+        self.nmr_embed = nn.Embedding(nmr_vocab_size, embed_dim)
+        self.memory_proj = nn.Linear(memory_dim, embed_dim) if memory_dim != embed_dim else nn.Identity()
+        self.layers = nn.ModuleList([
+            DecoderPromptLayer(d_model=embed_dim, memory_dim=memory_dim, nhead=num_heads, d_ffn=embed_dim * 4,
+                               dropout=dropout, use_rope=True, use_stablemax=use_stablemax) for _ in range(num_layers)])
+        self.final_norm = nn.LayerNorm(embed_dim)
+        self.out = nn.Linear(embed_dim, smiles_vocab_size)
+
+    def build_prompt(self, memory, nmr_tokens, dt):
+        """Truncation rules of reference :235-243, memory_proj (:259), NMR embedding and concat (:272-282)."""
+        if memory.size(1) > self.max_memory_length:
+            memory = memory[:, :self.max_memory_length]
+        if nmr_tokens is not None and nmr_tokens.size(1) > self.max_nmr_length:
+            nmr_tokens = nmr_tokens[:, :self.max_nmr_length]
+        memory = memory.to(dt)
+        if not isinstance(self.memory_proj, nn.Identity):
+            memory = _lin(memory, self.memory_proj, dt)
+        if nmr_tokens is None:
+            return memory
+        return th.cat([memory, self.nmr_embed(nmr_tokens.to(memory.device)).to(dt)], dim=1)
+
+    def forward(self, tgt, memory, nmr_tokens=None):
+        B, T = tgt.shape
+        dt = FN.get_compute_dtype()
+        prompt = self.build_prompt(memory, nmr_tokens, dt)
+        M = prompt.shape[1]
+        if T + M > self.max_seq_length + 256:
+            raise ValueError(f"Combined sequence length ({T} + {M} = {T + M}) "
+                             f"exceeds maximum length ({self.max_seq_length + 256})")
+        x = th.cat([prompt, self.smiles_embed(tgt).to(dt)], dim=1)
+        for layer in self.layers:
+            x = layer(x, None, prompt_len=M)
+        xt = FN.LayerNorm.apply(x[:, M:], self.final_norm.weight, self.final_norm.bias)
+        return _lin(xt, self.out, dt).float()

@@ -301,3 +301,28 @@ def decode_attn(q: Tensor, k_new: Tensor, v_new: Tensor, kcache: Tensor, vcache:
                                    L.ptr(sin_t), B, H, d, rot, pos, kcache.shape[2], q.stride(0), int(stablemax),
                                    L.dtype_code(q), L.cur_stream()), "mm_decode_attn")
     return o
+
+
+# --------------------------------------------------------------------------- small pieces
+def layerscale_bwd(dout: Tensor, z: Tensor, gamma: Tensor, rowscale: Optional[Tensor], rows_per_scale: int):
+    _chk(dout, "dout"); _chk(z, "z", dout.dtype)
+    M, Cc = dout.shape
+    dz = torch.empty_like(dout)
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=dout.device)
+    dbias = torch.empty_like(dgamma)
+    nbytes = L.lib().mm_layerscale_bwd_workspace(M, Cc)
+    ws = workspace(nbytes, dout.device)
+    L.check(L.lib().mm_layerscale_bwd(L.ptr(dout), L.ptr(z), L.ptr(_f32(gamma, "gamma")), L.ptr(rowscale), rows_per_scale,
+                                      L.ptr(dz), L.ptr(dgamma), L.ptr(dbias), L.ptr(ws), nbytes, M, Cc, L.dtype_code(dout),
+                                      L.cur_stream()), "mm_layerscale_bwd")
+    return dz, dgamma, dbias
+
+
+def argmax_rows(logits: Tensor) -> Tensor:
+    """logits [rows, V] (unit inner stride) -> int64 [rows]."""
+    if not logits.is_cuda or logits.dim() != 2 or logits.stride(1) != 1:
+        raise RuntimeError("argmax_rows: expected a 2-D GPU tensor with unit inner stride")
+    out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    L.check(L.lib().mm_argmax_rows(L.ptr(logits), L.ptr(out), logits.shape[0], logits.shape[1], logits.stride(0),
+                                   L.dtype_code(logits), L.cur_stream()), "mm_argmax_rows")
+    return out

@@ -1,0 +1,163 @@
+"""End-to-end GPU parity of the product modules (multimodal_amd.models, HIP path through the C ABI) against
+(1) the committed golden vectors produced by the reference itself and (2) the CPU oracle on the same inputs.
+Tolerances (BASELINE.json north_star): fp32 1e-4 relative on encoder/attention outputs, bf16 2e-2; greedy ids equal."""
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, case_inputs, cfg_of, load_golden, rel_err
+from oracle import fill, restate
+from oracle.shapes import formula_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(case, dtype=torch.float32):
+    import multimodal_amd as mm
+    from multimodal_amd.models import MultiModalToSMILESModel
+    m = MultiModalToSMILESModel(591, 1000, max_seq_length=case["max_seq"], max_nmr_length=case["max_nmr"],
+                                max_memory_length=case["max_mem"], embed_dim=case["E"], num_heads=case["H"],
+                                num_layers=case["L"], dropout=0.0, verbose=False, use_stablemax=case["sm"])
+    fill.fill_state_dict_(m, seed=0)
+    mm.set_compute_dtype(dtype)
+    return m.to(DEV).eval()
+
+
+@pytest.fixture(autouse=True)
+def _reset_dtype():
+    import multimodal_amd as mm
+    yield
+    mm.set_compute_dtype(torch.float32)
+
+
+def test_state_dict_loads_strict(golden_meta):
+    case = golden_meta["cases"]["tiny_sm"]
+    m = build(case)
+    sd = formula_state_dict(cfg_of(case))
+    m.load_state_dict(sd, strict=True)            # reference-shaped checkpoint: same keys, same shapes
+
+
+@pytest.mark.parametrize("name", ["tiny_sm", "d100_sm", "d128_sdpa", "d192_sm", "d512_sm", "test_config"])
+def test_forward_fp32_vs_reference_golden(golden_meta, name):
+    case = golden_meta["cases"][name]
+    m = build(case)
+    ir, nmr, tgt = case_inputs(case)
+    g = load_golden(name)
+    with torch.no_grad():
+        mem = m.encoder(None, ir.to(DEV), None)
+        logits = m(nmr.to(DEV), ir.to(DEV), tgt[:, :-1].to(DEV), None)
+    assert rel_err(mem[:2].float().cpu(), g["memory"]) < 1e-4
+    assert rel_err(logits.cpu(), g["logits"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["tiny_sm", "d100_sm", "d128_sdpa", "d192_sm", "d512_sm"])
+def test_forward_bf16_vs_reference_golden(golden_meta, name):
+    case = golden_meta["cases"][name]
+    m = build(case, torch.bfloat16)
+    ir, nmr, tgt = case_inputs(case)
+    g = load_golden(name)
+    with torch.no_grad():
+        mem = m.encoder(None, ir.to(DEV), None)
+        logits = m(nmr.to(DEV), ir.to(DEV), tgt[:, :-1].to(DEV), None)
+    assert rel_err(mem[:2].float().cpu(), g["memory"]) < 2e-2
+    assert rel_err(logits.cpu(), g["logits"]) < 5e-2       # 2e-2 per op; the logits sit behind L decoder layers
+
+
+@pytest.mark.parametrize("name", ["tiny_sm", "d100_sm", "d128_sdpa"])
+def test_backward_fp32_vs_reference_golden(golden_meta, name):
+    case = golden_meta["cases"][name]
+    m = build(case)
+    ir, nmr, tgt = case_inputs(case)
+    g = load_golden(name)
+    ir_d = ir.to(DEV).requires_grad_(True)
+    tg = tgt.to(DEV)
+    logits = m(nmr.to(DEV), ir_d, tg[:, :-1], None)
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.size(-1)), tg[:, 1:].reshape(-1), ignore_index=0)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert rel_err(ir_d.grad.cpu(), g["grad.ir"]) < 1e-3
+    grads = dict((k, p.grad) for k, p in m.named_parameters())
+    for k, v in g.items():
+        if k.startswith("grad.") and k != "grad.ir":
+            assert rel_err(grads[k[5:]].cpu(), v) < 1e-3, k
+    with open(os.path.join(GOLDEN, f"{name}.gradsums.json")) as fh:
+        sums = json.load(fh)
+    for k, (s, a) in sums.items():
+        got = float(grads[k].double().abs().sum())
+        assert abs(got - a) <= 2e-3 * a + 1e-9, (k, got, a)
+
+
+def test_train_mode_droppath_vs_reference_golden(golden_meta, monkeypatch):
+    """DropPath draws torch.rand((B,1,1)) per block in block order (convnext.py:15); the draws are taken from the
+    CPU generator here so the stream equals the one the golden vector was produced with."""
+    import multimodal_amd.models.convnext as cx
+    case = golden_meta["cases"]["tiny_sm"]
+    m = build(case).train()
+    ir, nmr, tgt = case_inputs(case)
+    g = load_golden("tiny_sm")
+    real_rand = torch.rand
+
+    def cpu_rand(shape, dtype=None, device=None):
+        return real_rand(shape, dtype=dtype).to(device)
+    monkeypatch.setattr(cx.torch, "rand", cpu_rand)
+    torch.manual_seed(2024)
+    with torch.no_grad():
+        logits = m(nmr.to(DEV), ir.to(DEV), tgt[:, :-1].to(DEV), None)
+    assert rel_err(logits.cpu(), g["logits_train_seed2024"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["tiny_sm", "d100_sm", "d128_sdpa", "test_config"])
+def test_greedy_generate_ids_equal_reference(golden_meta, name):
+    from multimodal_amd.generate import ids_to_lists
+    case = golden_meta["cases"][name]
+    m = build(case)
+    gold = golden_meta["greedy"][name]
+    ir8 = fill.synth_ir(8, 1000, 5).to(DEV)
+    nmr8 = fill.synth_tokens(8, case["N"], 0, 1000, 5).to(DEV)
+    toks = m.generate(nmr8, ir8, max_len=gold["max_len"])
+    assert ids_to_lists(toks.cpu()) == gold["ids"]
+
+
+def test_greedy_strings_equal_oracle(golden_meta):
+    from multimodal_amd.generate import ids_to_strings
+    from multimodal_amd.models import SmilesTokenizer
+    case = golden_meta["cases"]["tiny_sm"]
+    m = build(case)
+    tok = SmilesTokenizer(os.path.join(GOLDEN, "vocab.txt"))
+    ir8 = fill.synth_ir(8, 1000, 5)
+    nmr8 = fill.synth_tokens(8, case["N"], 0, 1000, 5)
+    toks = m.generate(nmr8.to(DEV), ir8.to(DEV), max_len=24)
+    got = ids_to_strings(toks.cpu(), tok)
+    cfg = cfg_of(case)
+    seqs = restate.greedy_decode_ids(formula_state_dict(cfg), cfg, nmr8, ir8, 24)
+    want = [restate.ids_to_string(s, tok.ids_to_tokens) for s in seqs]
+    assert got == want
+
+
+def test_block_api_bcl_layout():
+    """ConvNeXtBlock1D.forward keeps the reference's [B,C,L] signature."""
+    from multimodal_amd.models import ConvNeXtBlock1D
+    blk = ConvNeXtBlock1D(128, drop_path=0.0, layer_scale_init_value=0.5)
+    fill.fill_state_dict_(blk, seed=3)
+    x = fill.synth_ir(2, 128 * 40, 1).view(2, 128, 40)
+    sd = {"b." + k: v for k, v in blk.state_dict().items()}
+    ref = restate.convnext_block(sd, "b.", x)
+    y = blk.to(DEV).eval()(x.to(DEV))
+    assert y.shape == x.shape
+    assert rel_err(y.cpu(), ref) < 1e-4
+
+
+def test_cross_attention_block_vs_text_restatement():
+    """PARITY UNPINNED (reference class is dead code and cannot be imported): checked against oracle restatement."""
+    from multimodal_amd.models import CrossAttentionBlock
+    blk = CrossAttentionBlock(128, num_heads=4, dropout=0.0)
+    fill.fill_state_dict_(blk, seed=4)
+    q = fill.synth_ir(2, 9 * 128, 2).view(2, 9, 128) - 0.5
+    kv = fill.synth_ir(2, 31 * 128, 3).view(2, 31, 128) - 0.5
+    sd = {"x." + k: v for k, v in blk.state_dict().items()}
+    ref = restate.cross_attention_block(sd, "x.", q, kv, 4)
+    y = blk.to(DEV).eval()(q.to(DEV), kv.to(DEV))
+    assert rel_err(y.cpu(), ref) < 1e-4
