@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train spectra/s on synthetic spectra of the local/real_config shape (BASELINE.json
+configs[1]/[2]: E1600 H16 L8 stablemax, per-GPU batch 32, bf16 compute with f32 master weights), one process per
+GPU, gradient all-reduce on RCCL.  Also reports, in the same JSON line: the roofline of the fused dwconv7+LN kernel
+(K1) measured live with HIP events, greedy SMILES tokens/s with the KV cache (nocat shape), and the CPU baseline
+(the oracle's train step timed on the host cores, rank 0 at N=1 only).
+
+    python bench.py [--gpus N --steps K --warmup W]          # N>1: launched by torch.distributed.run
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # configs/local_config.yaml == configs/real_config.yaml (model section)
+    "local_config": dict(E=1600, H=16, L=8, sm=True, max_seq=95, max_nmr=190, max_mem=32),
+    "local_config_nocat": dict(E=1024, H=8, L=4, sm=False, max_seq=80, max_nmr=128, max_mem=64),
+    "test_config": dict(E=768, H=4, L=8, sm=True, max_seq=95, max_nmr=190, max_mem=32),
+    "real_config_mup": dict(E=2048, H=4, L=8, sm=True, max_seq=95, max_nmr=190, max_mem=32),
+}
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def build_model(c, device, seed=0):
+    from multimodal_amd.models import MultiModalToSMILESModel
+    torch.manual_seed(seed)
+    m = MultiModalToSMILESModel(591, 1000, max_seq_length=c["max_seq"], max_nmr_length=c["max_nmr"],
+                                max_memory_length=c["max_mem"], embed_dim=c["E"], num_heads=c["H"], num_layers=c["L"],
+                                dropout=0.0, verbose=False, use_stablemax=c["sm"])
+    return m.to(device)
+
+
+def synth_batch(c, B, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    ir = torch.rand(B, 1000, generator=g)
+    nmr = torch.randint(0, 1000, (B, c["max_nmr"]), generator=g)
+    tgt = torch.randint(15, 591, (B, c["max_seq"]), generator=g)
+    tgt[:, 0] = 12
+    return ir.to(device), nmr.to(device), tgt.to(device)
+
+
+def k1_roofline(device, dtype=torch.float32, B=8192, C=64, Ln=250, iters=20):
+    """Algorithmic bytes of K1 forward = B*C*L*(s_in+s_out) over the average launch time measured
+    with HIP events on the launch stream."""
+    from multimodal_amd import ops
+    x = torch.rand(B, Ln, C, device=device).to(dtype)
+    w = torch.randn(C, 1, 7, device=device) * 0.3
+    b = torch.zeros(C, device=device)
+    lw = torch.ones(C, device=device)
+    lb = torch.zeros(C, device=device)
+    for _ in range(3):
+        ops.dwconv7_ln_fwd(x, w, b, lw, lb)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        ops.dwconv7_ln_fwd(x, w, b, lw, lb)
+    e.record()
+    torch.cuda.synchronize()
+    t = s.elapsed_time(e) / iters * 1e-3
+    nbytes = B * C * Ln * 2 * x.element_size()
+    ach = nbytes / t / 1e9
+    return {"kernel": "dwconv7_ln_fwd_strip", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "launch_us": round(t * 1e6, 2),
+            "shape": {"B": B, "C": C, "L": Ln, "dtype": str(dtype).replace("torch.", "")},
+            "algorithmic_bytes_per_launch": nbytes}
+
+
+def greedy_bench(device, world, rank):
+    import multimodal_amd as mm
+    c = CONFIGS["local_config_nocat"]
+    B = max(1024 // world, 1)
+    m = build_model(c, device).eval()
+    ir, nmr, _ = synth_batch(c, B, device, 4321 + rank)
+    steps = c["max_seq"]
+    with mm.compute_dtype(torch.bfloat16):
+        m.generate(nmr[:8], ir[:8], max_len=4, early_stop=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        toks = m.generate(nmr, ir, max_len=steps, early_stop=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"tokens_per_s_per_gpu": round(B * (toks.shape[1] - 1) / dt, 1), "batch_per_gpu": B, "steps": toks.shape[1] - 1,
+            "config": "local_config_nocat", "dtype": "bf16", "kv_cache": True, "seconds": round(dt, 4)}
+
+
+def cpu_baseline(c, sample_b=2):
+    """The CPU oracle (oracle/restate.py, pinned against the reference) timed on the host cores: one train step
+    (forward + CE + backward + OrthoGrad + AdamW) of the same shape on a bounded batch."""
+    from oracle import restate
+    from oracle.shapes import state_shapes
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    torch.set_num_threads(cores)
+    cfg = restate.Cfg(embed_dim=c["E"], num_heads=c["H"], num_layers=c["L"], max_seq_length=c["max_seq"],
+                      max_nmr_length=c["max_nmr"], max_memory_length=c["max_mem"], use_stablemax=c["sm"])
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, shp in state_shapes(cfg).items():
+        if k.endswith("inv_freq"):
+            continue
+        if k.endswith("norm.weight") or ".1.weight" in k or ".0.2.weight" in k:
+            t = torch.ones(shp)
+        elif k.endswith("gamma"):
+            t = torch.full(shp, 1e-6)
+        elif k.endswith("bias"):
+            t = torch.zeros(shp)
+        else:
+            t = torch.randn(shp, generator=g) * 0.02
+        sd[k] = t.requires_grad_(True)
+    params = list(sd.values())
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
+    ir, nmr, tgt = synth_batch(c, sample_b, "cpu", 1234)
+    t0 = time.perf_counter()
+    loss = restate.train_loss(sd, cfg, nmr, ir, tgt, training=True)
+    opt.zero_grad()
+    loss.backward()
+    restate.orthograd_project_(params, eps=1e-8)
+    opt.step()
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_b / dt, 3), "unit": "spectra/s", "cores": cores, "kind": "port",
+            "sample": f"1 train step (fwd+CE+bwd+OrthoGrad+AdamW), fp32, local_config shape, batch {sample_b}, "
+                      f"N=190 T=94, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="local_config")
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (configs/*.yaml: training.batch_size = 32)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / greedy / cpu baseline legs")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import multimodal_amd as mm
+    from multimodal_amd.dp import DataParallel
+    from multimodal_amd.optim import OrthoGradAdamW
+    c = CONFIGS[a.config]
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    mm.set_compute_dtype(dt)
+    model = build_model(c, device).train()
+    dp = DataParallel(model)
+    # optimizer of configs/local_config.yaml: ortho_adamw, lr 1e-4, betas (0.9,0.999), wd 0.01, ortho eps 1e-8, rescale
+    opt = OrthoGradAdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, ortho=True,
+                         ortho_eps=1e-8, rescale=True)
+    ir, nmr, tgt = synth_batch(c, a.batch, device, 1234 + rank)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=0)
+    loss_acc = torch.zeros((), device=device)
+
+    def step(i):
+        for gparam in opt.param_groups:                       # linear warm-up (train_autoregressive.py:195-226)
+            gparam["lr"] = 1e-4 * min(1.0, (i + 1) / 100.0)
+        dp.zero_grad()
+        logits = model(nmr, ir, tgt[:, :-1], None)
+        loss = crit(logits.reshape(-1, logits.size(-1)), tgt[:, 1:].reshape(-1))
+        loss.backward()
+        dp.finish()
+        opt.step()
+        loss_acc.add_(loss.detach())
+
+    for i in range(a.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    final_loss = float(loss_acc.item()) / max(1, a.steps + a.warmup)
+
+    extras = {}
+    if not a.no_extras:
+        del opt, dp
+        model = None
+        torch.cuda.empty_cache()
+        roof = k1_roofline(device)
+        roof_bf16 = k1_roofline(device, torch.bfloat16)
+        greedy = greedy_bench(device, world, rank)
+        if world > 1:
+            gt = torch.tensor([greedy["tokens_per_s_per_gpu"]], device=device, dtype=torch.float64)
+            dist.all_reduce(gt, op=dist.ReduceOp.SUM)
+            greedy["tokens_per_s"] = round(float(gt.item()), 1)
+        else:
+            greedy["tokens_per_s"] = greedy["tokens_per_s_per_gpu"]
+        extras = {"roofline": roof, "roofline_bf16": roof_bf16, "greedy": greedy}
+        if rank == 0 and world == 1:
+            extras["cpu_baseline"] = cpu_baseline(c)
+
+    if rank == 0:
+        gb = a.batch * world
+        out = {
+            "metric": "train spectra/sec", "value": round(gb * a.steps / elapsed, 2), "unit": "spectra/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"configs/{a.config}.yaml train step (fwd + CE + bwd + grad all-reduce + OrthoGrad-AdamW), "
+                                   f"E{c['E']} H{c['H']} L{c['L']} {'stablemax' if c['sm'] else 'softmax'}, N={c['max_nmr']} "
+                                   f"T={c['max_seq'] - 1} S={31 + c['max_nmr'] + c['max_seq'] - 1}",
+                       "global_batch": gb, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
+                       "master_weights": "f32", "random_init": True},
+            "mean_loss": round(final_loss, 4),
+        }
+        out.update(extras)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -159,6 +159,18 @@ int mm_layerscale_bwd(const void* dout, const void* z, const float* gamma, const
  * the first maximal index wins, as torch.argmax does. */
 int mm_argmax_rows(const void* logits, int64_t* out, int64_t rows, int64_t V, int64_t ld, int dtype, void* stream);
 
+/* ---- optimizer: OrthoGrad projection + AdamW, multi-tensor (next-row N3) ---------------------
+ * replaces ortho_grad.py:60-99 + torch.optim.AdamW.step.  All tables are DEVICE arrays the caller builds once:
+ * descs[n_tensors]; the parameters are cut into chunks of chunk_elems elements: chunk_tensor[c], chunk_off[c];
+ * tensor_chunk_start[n_tensors+1] (chunks of a tensor are consecutive).  g is overwritten with the projected
+ * gradient (as the reference does), p/m/v are updated in place.  step counts from 1. */
+typedef struct { float* p; float* g; float* m; float* v; int64_t n; } mm_param_desc;
+size_t mm_orthograd_adamw_workspace(int64_t n_tensors, int64_t n_chunks);
+int mm_orthograd_adamw(const mm_param_desc* descs, const int32_t* chunk_tensor, const int64_t* chunk_off,
+                       const int32_t* tensor_chunk_start, int64_t n_tensors, int64_t n_chunks, int64_t chunk_elems,
+                       float lr, float beta1, float beta2, float adam_eps, float weight_decay, int64_t step,
+                       float ortho_eps, int rescale, int do_ortho, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,3 +96,92 @@ extern "C" int mm_argmax_rows(const void* logits, int64_t* out, int64_t rows, in
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// OrthoGrad projection + AdamW, multi-tensor, two passes over the parameters (reference ortho_grad.py:60-99
+// followed by torch.optim.AdamW.step):
+//   pass 1  per chunk: partial (w.w, w.g, g.g)        -> finalize per tensor: proj = w.g/(w.w+eps),
+//           |g_orth|^2 = g.g - 2 proj w.g + proj^2 w.w, scale = |g| / (|g_orth| + eps)   (rescale)
+//   pass 2  g <- (g - proj w) * scale;  AdamW update of p, m, v with that g.
+// Tables (device memory, built once by the caller): descs[n_tensors], chunk_tensor[n_chunks],
+// chunk_off[n_chunks], tensor_chunk_start[n_tensors+1].  Deterministic (fixed-order sums, f64 finalize).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void og_reduce_k(const mm_param_desc* __restrict__ descs, const int* __restrict__ chunk_tensor,
+                                                  const long* __restrict__ chunk_off, int chunk_elems, float* __restrict__ part) {
+    __shared__ float red[3][4];
+    const mm_param_desc d = descs[chunk_tensor[blockIdx.x]];
+    const long off = chunk_off[blockIdx.x];
+    const long end = min(d.n, off + (long)chunk_elems);
+    float ww = 0.f, wg = 0.f, gg = 0.f;
+    for (long i = off + threadIdx.x; i < end; i += 256) {
+        const float w = d.p[i], g = d.g[i];
+        ww = fmaf(w, w, ww); wg = fmaf(w, g, wg); gg = fmaf(g, g, gg);
+    }
+    ww = wave_sum(ww); wg = wave_sum(wg); gg = wave_sum(gg);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ww; red[1][threadIdx.x >> 6] = wg; red[2][threadIdx.x >> 6] = gg; }
+    __syncthreads();
+    if (threadIdx.x < 3) part[(long)blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+__global__ void og_finalize_k(const float* __restrict__ part, const int* __restrict__ tcs, int n_tensors, float ortho_eps,
+                              int rescale, float* __restrict__ coef) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= n_tensors) return;
+    double ww = 0, wg = 0, gg = 0;
+    for (int c = tcs[t]; c < tcs[t + 1]; c++) { ww += part[(long)c * 3]; wg += part[(long)c * 3 + 1]; gg += part[(long)c * 3 + 2]; }
+    const double proj = wg / (ww + (double)ortho_eps);
+    double scale = 1.0;
+    if (rescale) {
+        double go2 = gg - 2.0 * proj * wg + proj * proj * ww;
+        if (go2 < 0) go2 = 0;
+        scale = sqrt(gg) / (sqrt(go2) + (double)ortho_eps);
+    }
+    coef[2 * t] = (float)proj; coef[2 * t + 1] = (float)scale;
+}
+__global__ __launch_bounds__(256) void og_adamw_k(const mm_param_desc* __restrict__ descs, const int* __restrict__ chunk_tensor,
+                                                 const long* __restrict__ chunk_off, int chunk_elems, const float* __restrict__ coef,
+                                                 float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s) {
+    const int t = chunk_tensor[blockIdx.x];
+    const mm_param_desc d = descs[t];
+    const long off = chunk_off[blockIdx.x];
+    const long end = min(d.n, off + (long)chunk_elems);
+    const float proj = coef ? coef[2 * t] : 0.f, scale = coef ? coef[2 * t + 1] : 1.f;
+    const float step_size = lr / bc1;
+    for (long i = off + threadIdx.x; i < end; i += 256) {
+        float w = d.p[i];
+        float g = d.g[i];
+        if (coef) { g = (g - proj * w) * scale; d.g[i] = g; }
+        w *= 1.f - lr * wd;
+        const float m = b1 * d.m[i] + (1.f - b1) * g;
+        const float v = b2 * d.v[i] + (1.f - b2) * g * g;
+        d.m[i] = m; d.v[i] = v;
+        const float denom = sqrtf(v) / bc2s + eps;
+        d.p[i] = w - step_size * (m / denom);
+    }
+}
+extern "C" size_t mm_orthograd_adamw_workspace(int64_t n_tensors, int64_t n_chunks) {
+    return (n_tensors > 0 && n_chunks > 0) ? (size_t)(3 * n_chunks + 2 * n_tensors) * sizeof(float) : 0;
+}
+extern "C" int mm_orthograd_adamw(const mm_param_desc* descs, const int32_t* chunk_tensor, const int64_t* chunk_off,
+                                  const int32_t* tensor_chunk_start, int64_t n_tensors, int64_t n_chunks, int64_t chunk_elems,
+                                  float lr, float beta1, float beta2, float adam_eps, float weight_decay, int64_t step,
+                                  float ortho_eps, int rescale, int do_ortho, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    MM_CHECK(descs && chunk_tensor && chunk_off && tensor_chunk_start && workspace, "orthograd_adamw: null pointer");
+    MM_CHECK(n_tensors > 0 && n_chunks > 0 && chunk_elems > 0 && step >= 1, "orthograd_adamw: bad sizes/step");
+    MM_CHECK(workspace_bytes >= mm_orthograd_adamw_workspace(n_tensors, n_chunks), "orthograd_adamw: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    float* coef = part + 3 * n_chunks;
+    if (do_ortho) {
+        hipLaunchKernelGGL(og_reduce_k, dim3((unsigned)n_chunks), dim3(256), 0, st, descs, (const int*)chunk_tensor, (const long*)chunk_off, (int)chunk_elems, part);
+        MM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(og_finalize_k, dim3((unsigned)cdiv(n_tensors, 64)), dim3(64), 0, st, part, (const int*)tensor_chunk_start, (int)n_tensors, ortho_eps, rescale, coef);
+        MM_LAUNCH_CHECK();
+    }
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(og_adamw_k, dim3((unsigned)n_chunks), dim3(256), 0, st, descs, (const int*)chunk_tensor, (const long*)chunk_off, (int)chunk_elems,
+                       do_ortho ? coef : nullptr, lr, beta1, beta2, adam_eps, weight_decay, bc1, bc2s);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}

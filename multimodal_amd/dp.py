@@ -1,0 +1,99 @@
+"""Data-parallel training: one process per GPU, replicated weights, ONE exchange step -- the gradient all-reduce
+on RCCL over xGMI (torch.distributed backend "nccl" is RCCL on ROCm).  The reference is single-device
+(train_autoregressive.py:608); equivalence target = a single-process step on the concatenated global batch
+(SURVEY.md 8e).
+
+Gradients live permanently inside a few large flat buckets (p.grad are views), so a bucket is reduced in place
+with no packing copies; a bucket's all-reduce is launched from an autograd hook as soon as its last gradient has
+been accumulated, on RCCL's own stream, overlapping the rest of backward.  Buckets are filled in reverse
+parameter order (the order backward produces gradients).  Bucket size defaults to 128 MiB: xGMI is
+point-to-point (7 links x ~153 GB/s), large messages keep every link busy and 288 GB of HBM makes them free."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradBuckets:
+    def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 128 << 20, comm_dtype=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []           # dicts: flat, params, pending, work
+        cur, cur_n = [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n * 4 >= bucket_bytes:
+                self._make(cur)
+                cur, cur_n = [], 0
+        if cur:
+            self._make(cur)
+        self.comm_dtype = comm_dtype
+
+    def _make(self, plist):
+        n = sum(p.numel() for p in plist)
+        flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
+        off = 0
+        for p in plist:
+            p.grad = flat[off: off + p.numel()].view_as(p)
+            off += p.numel()
+        self.buckets.append(dict(flat=flat, params=list(plist), pending=len(plist), work=None))
+
+    def zero(self):
+        for b in self.buckets:
+            b["flat"].zero_()
+
+
+class DataParallel:
+    """Wraps a replicated module.  Usage per step:  dp.zero_grad(); loss.backward(); dp.finish(); optimizer.step()."""
+
+    def __init__(self, module: torch.nn.Module, process_group=None, bucket_bytes: int = 128 << 20, overlap: bool = True):
+        self.module = module
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.buckets = GradBuckets(list(module.parameters()), bucket_bytes)
+        self.overlap = overlap and self.world > 1
+        self._bucket_of = {}
+        for b in self.buckets.buckets:
+            for p in b["params"]:
+                self._bucket_of[p] = b
+        if self.world > 1:
+            self.broadcast_parameters()
+        if self.overlap:
+            for p in self.buckets.params:
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    def broadcast_parameters(self, src: int = 0):
+        for t in list(self.module.parameters()) + list(self.module.buffers()):
+            dist.broadcast(t.data, src, group=self.pg)
+
+    def _launch(self, b):
+        b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _hook(self, p):
+        b = self._bucket_of[p]
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def zero_grad(self):
+        self.buckets.zero()
+        for b in self.buckets.buckets:
+            b["pending"] = len(b["params"])
+            b["work"] = None
+
+    def finish(self):
+        """Wait for every bucket's all-reduce and average.  Parameters that received no gradient this step still
+        take part (their bucket slots are zero), so every rank issues the same collectives in the same order."""
+        if self.world == 1:
+            return
+        for b in self.buckets.buckets:
+            if b["work"] is None:
+                self._launch(b)
+        for b in self.buckets.buckets:
+            b["work"].wait()
+            b["flat"].mul_(1.0 / self.world)
+
+    def __call__(self, *a, **kw):
+        return self.module(*a, **kw)

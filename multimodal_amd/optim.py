@@ -1,0 +1,81 @@
+"""OrthoGrad + AdamW as one fused multi-tensor HIP pass (reference ortho_grad.py:19-99 wrapped around
+torch.optim.AdamW, as train_autoregressive.py:685-704 builds it).  State (exp_avg, exp_avg_sq, step) follows
+torch.optim.AdamW's math; parameters stay ordinary nn.Parameters."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+
+CHUNK = 1 << 16
+
+
+class ParamDesc(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
+
+
+class OrthoGradAdamW(torch.optim.Optimizer):
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                 ortho=True, ortho_eps=1e-30, rescale=True):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, ortho=ortho, ortho_eps=ortho_eps,
+                        rescale=rescale)
+        super().__init__(params, defaults)
+        self._tables = {}
+        self._step = 0
+
+    def _build(self, gi, plist):
+        dev = plist[0].device
+        descs = (ParamDesc * len(plist))()
+        ct, co, tcs = [], [], [0]
+        for t, p in enumerate(plist):
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            descs[t].p, descs[t].g = p.data_ptr(), p.grad.data_ptr()
+            descs[t].m, descs[t].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            descs[t].n = p.numel()
+            nch = (p.numel() + CHUNK - 1) // CHUNK
+            ct += [t] * nch
+            co += [i * CHUNK for i in range(nch)]
+            tcs.append(tcs[-1] + nch)
+        raw = np.frombuffer(bytes(descs), dtype=np.uint8)
+        tab = dict(
+            key=tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist),
+            descs=torch.from_numpy(raw.copy()).to(dev),
+            ct=torch.tensor(ct, dtype=torch.int32, device=dev), co=torch.tensor(co, dtype=torch.int64, device=dev),
+            tcs=torch.tensor(tcs, dtype=torch.int32, device=dev), n_tensors=len(plist), n_chunks=len(ct))
+        self._tables[gi] = tab
+        return tab
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._step += 1
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None]
+            if not plist:
+                continue
+            for p in plist:
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+                    raise RuntimeError("OrthoGradAdamW: float32 contiguous GPU parameters and gradients only")
+            tab = self._tables.get(gi)
+            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
+            if tab is None or tab["key"] != key:
+                tab = self._build(gi, plist)
+            nbytes = L.lib().mm_orthograd_adamw_workspace(tab["n_tensors"], tab["n_chunks"])
+            ws = ops.workspace(nbytes, plist[0].device, "optim")
+            b1, b2 = group["betas"]
+            L.check(L.lib().mm_orthograd_adamw(L.ptr(tab["descs"]), L.ptr(tab["ct"]), L.ptr(tab["co"]), L.ptr(tab["tcs"]),
+                                               tab["n_tensors"], tab["n_chunks"], CHUNK, group["lr"], b1, b2, group["eps"],
+                                               group["weight_decay"], self._step, group["ortho_eps"], int(group["rescale"]),
+                                               int(group["ortho"]), L.ptr(ws), nbytes, L.cur_stream()), "mm_orthograd_adamw")
+        return loss
