@@ -50,6 +50,23 @@ def bench_gemm(M, N, K, dtype, akm=False, bkm=False):
                 TFLOPs=2 * M * N * K / t / 1e12, torch_TFLOPs=2 * M * N * K / tt / 1e12)
 
 
+def bench_attn(B, H, d, S, P, dtype, stablemax=True):
+    dev = torch.device("cuda:0")
+    E = H * d
+    rot = int(d * 0.5); rot -= rot % 2
+    qkv = (torch.rand(B, S, 3, E, device=dev) * 2 - 1).to(dtype)
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2, device=dev).float() / rot))
+    cos_t, sin_t = ops.rope_tables(inv, S)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    o, lse = ops.prefix_attn_fwd(q, k, v, H, rot, P, cos_t, sin_t, stablemax, save_lse=True)
+    do = torch.randn_like(o)
+    tf = timeit(lambda: ops.prefix_attn_fwd(q, k, v, H, rot, P, cos_t, sin_t, stablemax, save_lse=True))
+    tb = timeit(lambda: ops.prefix_attn_bwd(q, k, v, o, do, lse, H, rot, P, cos_t, sin_t, stablemax))
+    fl = 4.0 * B * S * S * E
+    return dict(kernel="prefix_attn", B=B, H=H, d=d, S=S, P=P, dtype=str(dtype), stablemax=stablemax, fwd_us=tf * 1e6,
+                bwd_us=tb * 1e6, fwd_TFLOPs=fl / tf / 1e12, bwd_TFLOPs=2.5 * fl / tb / 1e12)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="k1,gemm")
@@ -67,3 +84,6 @@ if __name__ == "__main__":
                 res.append(bench_gemm(M, N, K, dt)); print(json.dumps(res[-1]), flush=True)
             res.append(bench_gemm(10080, 1600, 6400, dt, False, True)); print(json.dumps(res[-1]), flush=True)
             res.append(bench_gemm(6400, 1600, 10080, dt, True, True)); print(json.dumps(res[-1]), flush=True)
+    if "attn" in a.what:
+        for (B, H, d, S, P, sm) in [(32, 16, 100, 315, 221, True), (32, 8, 128, 238, 159, False), (32, 4, 192, 315, 221, True), (32, 4, 512, 315, 221, True)]:
+            res.append(bench_attn(B, H, d, S, P, torch.bfloat16, sm)); print(json.dumps(res[-1]), flush=True)

@@ -631,6 +631,287 @@ __global__ __launch_bounds__(64) void prefix_attn_bwd_dkv_k(const AttnP p) {
                      (void*)((T*)p.dk + (long)b * p.S * p.ld_d + (long)h * p.d), p.ld_d, BF);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 backward, 4 waves per workgroup: the streamed tiles (K/V for dQ, Q/dO for dK/dV) are staged once
+// per 64 stationary rows and shared by the 4 waves; each wave keeps its 16 stationary rows as MFMA
+// B-fragments in registers.  Same arithmetic and lane maps as the one-wave kernels above.
+// ------------------------------------------------------------------------------------------------
+template <int DP, bool STABLE>
+__global__ __launch_bounds__(256) void prefix_attn_bwd_dq4_k(const AttnP p) {
+    typedef bf16 T;
+    constexpr int KT = 32, PITCH = DP + 8;
+    constexpr int NKS = DP / 32, NDV = DP / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* lk = reinterpret_cast<T*>(smem);
+    T* lv = lk + KT * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = blockIdx.x * 64;
+    const long head_off = (long)b * p.S * p.ld + (long)h * p.d;
+    const T* qg = (const T*)p.q + head_off;
+    const T* kg = (const T*)p.k + head_off;
+    const T* vg = (const T*)p.v + head_off;
+    const T* dog = (const T*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d;
+    bf16x8_t qf[NKS], gf[NKS];
+    for (int w = 0; w < 4; w++) {
+        stage_rows<T, DP>(lk, PITCH, qg, p.ld, q0 + 16 * w, 16, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP>(lv, PITCH, dog, p.ld_o, q0 + 16 * w, 16, p.S, p.d, p.vec_ok);
+        __syncthreads();
+        rope_rows<T>(lk, PITCH, q0 + 16 * w, 16, p.S, p.rot, p.cos_t, p.sin_t, false);
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                qf[ks] = *reinterpret_cast<const bf16x8_t*>(&lk[fr * PITCH + ks * 32 + fg * 8]);
+                gf[ks] = *reinterpret_cast<const bf16x8_t*>(&lv[fr * PITCH + ks * 32 + fg * 8]);
+            }
+        }
+        __syncthreads();
+    }
+    const int qw0 = q0 + 16 * wave;
+    const int qi = qw0 + fr;
+    const bool qok = qi < p.S;
+    const long stat = ((long)b * p.H + h) * p.S + (qok ? qi : 0);
+    const float lse = p.lse[stat], dlt = p.delta[stat];
+    const float invL = STABLE ? 1.0f / fmaxf(lse, 1e-9f) : 0.f;
+    auto key_end = [&](int qlo, int qhi) {
+        int e = min(qhi, p.S - 1) + 1;
+        if (qlo < p.P) e = max(e, p.P);
+        return min(e, p.S);
+    };
+    const int kend_blk = key_end(q0, q0 + 63);
+    const int kend_w = (qw0 < p.S) ? key_end(qw0, qw0 + 15) : 0;
+
+    f32x4_t dqa[NDV];
+#pragma unroll
+    for (int n = 0; n < NDV; n++) dqa[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < kend_blk; k0 += KT) {
+        stage_rows<T, DP>(lk, PITCH, kg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP>(lv, PITCH, vg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
+        __syncthreads();
+        rope_rows<T>(lk, PITCH, k0, KT, p.S, p.rot, p.cos_t, p.sin_t, false);
+        __syncthreads();
+        if (k0 < kend_w) {
+            f32x4_t sa[2], da[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                sa[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; da[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ks++) {
+                    const int off = ks * 32 + fg * 8;
+                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&lk[(16 * t + fr) * PITCH + off]);
+                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(&lv[(16 * t + fr) * PITCH + off]);
+                    sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sa[t], 0, 0, 0);
+                    da[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[ks], da[t], 0, 0, 0);
+                }
+            }
+            bf16x8_t dsf;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int kj = k0 + 16 * t + 4 * fg + r;
+                    const float x = sa[t][r] * p.scale;
+                    float ds = 0.f;
+                    if (qok && attn_allowed(qi, kj, p.P, p.S)) {
+                        if (STABLE) { const float sx = stable_s_f(x); ds = (da[t][r] - dlt) * invL * (x < 0.f ? sx * sx : 1.f); }
+                        else { const float pr = __expf(x - lse); ds = pr * (da[t][r] - dlt); }
+                    }
+                    dsf[4 * t + r] = (short)f2bf(ds);
+                }
+            typedef bf16x4_t __attribute__((address_space(3))) * lds4p;
+            const int qq = fr >> 2, pp = fr & 3;
+#pragma unroll
+            for (int n = 0; n < NDV; n++) {
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lk[(4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lk[(16 + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                const bf16x8_t kt = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                dqa[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf, dqa[n], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* stg = reinterpret_cast<float*>(lk);
+    constexpr int SP = DP + 1;
+    for (int w = 0; w < 4; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int n = 0; n < NDV; n++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) stg[fr * SP + 16 * n + 4 * fg + e] = dqa[n][e] * p.scale;
+        }
+        __syncthreads();
+        unrope_store<DP>(stg, SP, q0 + 16 * w, 16, p.S, p.d, p.rot, p.cos_t, p.sin_t, p.rot > 0,
+                         (void*)((T*)p.dq + (long)b * p.S * p.ld_d + (long)h * p.d), p.ld_d, true);
+        __syncthreads();
+    }
+}
+
+template <int DP, bool STABLE>
+__global__ __launch_bounds__(256) void prefix_attn_bwd_dkv4_k(const AttnP p) {
+    typedef bf16 T;
+    constexpr int QT = 32, PITCH = DP + 8;
+    constexpr int NKS = DP / 32, NDV = DP / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* lq = reinterpret_cast<T*>(smem);
+    T* ldo = lq + QT * PITCH;
+    float* lstat = reinterpret_cast<float*>(ldo + QT * PITCH);       // [2][QT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int kb0 = blockIdx.x * 64;
+    const long head_off = (long)b * p.S * p.ld + (long)h * p.d;
+    const T* qg = (const T*)p.q + head_off;
+    const T* kg = (const T*)p.k + head_off;
+    const T* vg = (const T*)p.v + head_off;
+    const T* dog = (const T*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d;
+    bf16x8_t kf[NKS], vf[NKS];
+    for (int w = 0; w < 4; w++) {
+        stage_rows<T, DP>(lq, PITCH, kg, p.ld, kb0 + 16 * w, 16, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP>(ldo, PITCH, vg, p.ld, kb0 + 16 * w, 16, p.S, p.d, p.vec_ok);
+        __syncthreads();
+        rope_rows<T>(lq, PITCH, kb0 + 16 * w, 16, p.S, p.rot, p.cos_t, p.sin_t, false);
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) {
+                kf[ks] = *reinterpret_cast<const bf16x8_t*>(&lq[fr * PITCH + ks * 32 + fg * 8]);
+                vf[ks] = *reinterpret_cast<const bf16x8_t*>(&ldo[fr * PITCH + ks * 32 + fg * 8]);
+            }
+        }
+        __syncthreads();
+    }
+    const int kw0 = kb0 + 16 * wave;
+    const int kj = kw0 + fr;
+    const long statbase = ((long)b * p.H + h) * p.S;
+    const int qstart_blk = (kb0 < p.P) ? 0 : (kb0 / QT) * QT;
+    const int qstart_w = (kw0 < p.P) ? 0 : kw0;        // first query that can see any key of this wave
+    const bool wave_live = kw0 < p.S;
+
+    f32x4_t dka[NDV], dva[NDV];
+#pragma unroll
+    for (int n = 0; n < NDV; n++) { dka[n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dva[n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int q0 = qstart_blk; q0 < p.S; q0 += QT) {
+        stage_rows<T, DP>(lq, PITCH, qg, p.ld, q0, QT, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP>(ldo, PITCH, dog, p.ld_o, q0, QT, p.S, p.d, p.vec_ok);
+        if (tid < QT) {
+            const int qi = q0 + tid;
+            lstat[tid] = qi < p.S ? p.lse[statbase + qi] : 1.f;
+            lstat[QT + tid] = qi < p.S ? p.delta[statbase + qi] : 0.f;
+        }
+        __syncthreads();
+        rope_rows<T>(lq, PITCH, q0, QT, p.S, p.rot, p.cos_t, p.sin_t, false);
+        __syncthreads();
+        if (wave_live && q0 + QT > qstart_w) {
+            f32x4_t sa[2], da[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                sa[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; da[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ks++) {
+                    const int off = ks * 32 + fg * 8;
+                    const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(&lq[(16 * t + fr) * PITCH + off]);
+                    const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(&ldo[(16 * t + fr) * PITCH + off]);
+                    sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], sa[t], 0, 0, 0);
+                    da[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf[ks], da[t], 0, 0, 0);
+                }
+            }
+            bf16x8_t pf, dsf;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int ql = 16 * t + 4 * fg + r;
+                    const int qi = q0 + ql;
+                    const float x = sa[t][r] * p.scale;
+                    float pr = 0.f, ds = 0.f;
+                    if (qi < p.S && attn_allowed(qi, kj, p.P, p.S)) {
+                        const float lse = lstat[ql], dlt = lstat[QT + ql];
+                        if (STABLE) {
+                            const float sx = stable_s_f(x), invL = 1.0f / fmaxf(lse, 1e-9f);
+                            pr = sx * invL; ds = (da[t][r] - dlt) * invL * (x < 0.f ? sx * sx : 1.f);
+                        } else { pr = __expf(x - lse); ds = pr * (da[t][r] - dlt); }
+                    }
+                    pf[4 * t + r] = (short)f2bf(pr); dsf[4 * t + r] = (short)f2bf(ds);
+                }
+            typedef bf16x4_t __attribute__((address_space(3))) * lds4p;
+            const int qq = fr >> 2, pp = fr & 3;
+#pragma unroll
+            for (int n = 0; n < NDV; n++) {
+                const bf16x4_t glo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&ldo[(4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                const bf16x4_t ghi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&ldo[(16 + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                const bf16x8_t gt = bf16x8_t{glo[0], glo[1], glo[2], glo[3], ghi[0], ghi[1], ghi[2], ghi[3]};
+                dva[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf, dva[n], 0, 0, 0);
+                const bf16x4_t qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lq[(4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                const bf16x4_t qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lq[(16 + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                const bf16x8_t qt = bf16x8_t{qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+                dka[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf, dka[n], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* stg = reinterpret_cast<float*>(lq);
+    constexpr int SP = DP + 1;
+    for (int w = 0; w < 4; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int n = 0; n < NDV; n++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) stg[fr * SP + 16 * n + 4 * fg + e] = dva[n][e];
+        }
+        __syncthreads();
+        unrope_store<DP>(stg, SP, kb0 + 16 * w, 16, p.S, p.d, 0, p.cos_t, p.sin_t, false,
+                         (void*)((T*)p.dv + (long)b * p.S * p.ld_d + (long)h * p.d), p.ld_d, true);
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int n = 0; n < NDV; n++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) stg[fr * SP + 16 * n + 4 * fg + e] = dka[n][e] * p.scale;
+        }
+        __syncthreads();
+        unrope_store<DP>(stg, SP, kb0 + 16 * w, 16, p.S, p.d, p.rot, p.cos_t, p.sin_t, p.rot > 0,
+                         (void*)((T*)p.dk + (long)b * p.S * p.ld_d + (long)h * p.d), p.ld_d, true);
+        __syncthreads();
+    }
+}
+
+template <int DP>
+static int bwd_launch4(const AttnP& p, int mode, hipStream_t st) {
+    constexpr int PITCH = DP + 8;
+    const size_t lds = (size_t)2 * 32 * PITCH * 2 + 2 * 32 * sizeof(float);
+    const dim3 grid((unsigned)cdiv(p.S, 64), (unsigned)(p.B * p.H));
+#define SETATTR_(K_) if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    if (mode == MM_ATTN_STABLEMAX) {
+        SETATTR_((prefix_attn_bwd_dq4_k<DP, true>));
+        hipLaunchKernelGGL((prefix_attn_bwd_dq4_k<DP, true>), grid, dim3(256), lds, st, p);
+        SETATTR_((prefix_attn_bwd_dkv4_k<DP, true>));
+        hipLaunchKernelGGL((prefix_attn_bwd_dkv4_k<DP, true>), grid, dim3(256), lds, st, p);
+    } else {
+        SETATTR_((prefix_attn_bwd_dq4_k<DP, false>));
+        hipLaunchKernelGGL((prefix_attn_bwd_dq4_k<DP, false>), grid, dim3(256), lds, st, p);
+        SETATTR_((prefix_attn_bwd_dkv4_k<DP, false>));
+        hipLaunchKernelGGL((prefix_attn_bwd_dkv4_k<DP, false>), grid, dim3(256), lds, st, p);
+    }
+#undef SETATTR_
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+static int bwd_dispatch4(const AttnP& p, int mode, hipStream_t st) {
+    const int d = p.d;
+    if (d <= 32) return bwd_launch4<32>(p, mode, st);
+    if (d <= 64) return bwd_launch4<64>(p, mode, st);
+    if (d <= 128) return bwd_launch4<128>(p, mode, st);
+    if (d <= 192) return bwd_launch4<192>(p, mode, st);
+    if (d <= 256) return bwd_launch4<256>(p, mode, st);
+    if (d <= 512) return bwd_launch4<512>(p, mode, st);
+    MM_FAIL(MM_ERR_UNSUPPORTED, "prefix_attn_bwd: head_dim %d > 512", d);
+}
+
 template <typename T, int DP>
 static int bwd_launch(const AttnP& p, int mode, hipStream_t st) {
     constexpr int PITCH = DP + AT<T>::PAD, KT = AT<T>::KT;
@@ -694,7 +975,7 @@ extern "C" int mm_prefix_attn_bwd(const void* q, const void* k, const void* v, c
     hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, o, d_o, (float*)workspace, rows, (int)H, (int)S,
                        (int)d, (long)(H * d), (long)(H * d), dtype == MM_BF16 ? 1 : 0);
     MM_LAUNCH_CHECK();
-    return dtype == MM_BF16 ? bwd_dispatch<bf16>(p, mode, st) : bwd_dispatch<float>(p, mode, st);
+    return dtype == MM_BF16 ? bwd_dispatch4(p, mode, st) : bwd_dispatch<float>(p, mode, st);
 }
 
 // ------------------------------------------------------------------------------------------------
