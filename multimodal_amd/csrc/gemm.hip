@@ -36,11 +36,14 @@ template <> struct Mma<float> {
 };
 
 // ---- guarded EPV-wide global load into raw storage ------------------------------------------------
-template <typename T, int E>
+template <typename T, int E, bool FAST>
 __device__ __forceinline__ void load_vec(const T* __restrict__ base, bool vec_ok, long slow, long slow_lim, long fast,
                                          long fast_lim, long ld, T (&out)[E]) {
-    if (slow < slow_lim && vec_ok && fast + E <= fast_lim) {
-        typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    if constexpr (FAST) {       // host guarantees: 16-byte aligned rows and a contiguous extent that is a multiple of E
+        if (slow < slow_lim && fast < fast_lim) *reinterpret_cast<u4*>(&out[0]) = *reinterpret_cast<const u4*>(base + slow * ld + fast);
+        else *reinterpret_cast<u4*>(&out[0]) = u4{0u, 0u, 0u, 0u};
+    } else if (slow < slow_lim && vec_ok && fast + E <= fast_lim) {
         *reinterpret_cast<u4*>(&out[0]) = *reinterpret_cast<const u4*>(base + slow * ld + fast);
     } else {
 #pragma unroll
@@ -60,8 +63,11 @@ __device__ __forceinline__ float act_bwd(int act, float pre) {
     return 1.f;
 }
 
-template <typename T, typename TO, int BM, int BN, bool AKM, bool BKM>
-__global__ __launch_bounds__(256) void gemm_k(const GemmP p) {
+template <typename T, typename TO, int BM, int BN, bool AKM, bool BKM, bool FAST>
+#ifndef GEMM_MIN_WAVES
+#define GEMM_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(256, GEMM_MIN_WAVES) void gemm_k(const GemmP p) {
     constexpr int BK = Mma<T>::BK, EPV = Mma<T>::EPV, PAD = Mma<T>::PAD;
     constexpr bool IS_BF16 = sizeof(T) == 2;
     // LDS images.  bf16: K-contiguous -> [ROWS][BK+PAD];  K-major -> [BK][ROWS+PAD].  f32: always [ROWS][BK+1].
@@ -91,23 +97,24 @@ __global__ __launch_bounds__(256) void gemm_k(const GemmP p) {
     const T* __restrict__ A = (const T*)p.A;
     const T* __restrict__ B = (const T*)p.B;
 
-    T ra[NVA][EPV], rb[NVB][EPV];
+    alignas(16) T ra[NVA][EPV];
+    alignas(16) T rb[NVB][EPV];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NVA; i++) {
             const int v = tid + 256 * i;
             if (!AKM) { const int row = v / (BK / EPV), kc = v % (BK / EPV);
-                load_vec<T, EPV>(A, p.a_vec, m0 + row, p.M, k0 + kc * EPV, kend, p.lda, ra[i]); }
+                load_vec<T, EPV, FAST>(A, p.a_vec, m0 + row, p.M, k0 + kc * EPV, kend, p.lda, ra[i]); }
             else { const int k = v / (BM / EPV), rc = v % (BM / EPV);
-                load_vec<T, EPV>(A, p.a_vec, k0 + k, kend, m0 + rc * EPV, p.M, p.lda, ra[i]); }
+                load_vec<T, EPV, FAST>(A, p.a_vec, k0 + k, kend, m0 + rc * EPV, p.M, p.lda, ra[i]); }
         }
 #pragma unroll
         for (int i = 0; i < NVB; i++) {
             const int v = tid + 256 * i;
             if (!BKM) { const int row = v / (BK / EPV), kc = v % (BK / EPV);
-                load_vec<T, EPV>(B, p.b_vec, n0 + row, p.N, k0 + kc * EPV, kend, p.ldb, rb[i]); }
+                load_vec<T, EPV, FAST>(B, p.b_vec, n0 + row, p.N, k0 + kc * EPV, kend, p.ldb, rb[i]); }
             else { const int k = v / (BN / EPV), rc = v % (BN / EPV);
-                load_vec<T, EPV>(B, p.b_vec, k0 + k, kend, n0 + rc * EPV, p.N, p.ldb, rb[i]); }
+                load_vec<T, EPV, FAST>(B, p.b_vec, k0 + k, kend, n0 + rc * EPV, p.N, p.ldb, rb[i]); }
         }
     };
     auto stash = [&]() {
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(256) void gemm_k(const GemmP p) {
                 for (int e = 0; e < 4; e++) if (n + e < p.N) dst[e] = v[e];
                 continue;
             }
-            const bool full = p.o_vec && n + 4 <= p.N;
+            const bool full = FAST || (p.o_vec && n + 4 <= p.N);
             const long off = m * p.ldo + n;
             if (p.bias) {
 #pragma unroll
@@ -292,12 +299,22 @@ __global__ void splitk_reduce_k(const float* __restrict__ partial, int splits, l
     out[m * ldo + n] = from_f<TO>(s);
 }
 
+template <typename T, typename TO, int BM, int BN, bool FAST>
+static void launch_layout2(const GemmP& p, int akm, int bkm, dim3 grid, hipStream_t st) {
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_k<T, TO, BM, BN, false, false, FAST>), grid, dim3(256), 0, st, p);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_k<T, TO, BM, BN, false, true, FAST>), grid, dim3(256), 0, st, p);
+    else if (akm && bkm) hipLaunchKernelGGL((gemm_k<T, TO, BM, BN, true, true, FAST>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_k<T, TO, BM, BN, true, false, FAST>), grid, dim3(256), 0, st, p);
+}
 template <typename T, typename TO, int BM, int BN>
 static void launch_layout(const GemmP& p, int akm, int bkm, dim3 grid, hipStream_t st) {
-    if (!akm && !bkm) hipLaunchKernelGGL((gemm_k<T, TO, BM, BN, false, false>), grid, dim3(256), 0, st, p);
-    else if (!akm && bkm) hipLaunchKernelGGL((gemm_k<T, TO, BM, BN, false, true>), grid, dim3(256), 0, st, p);
-    else if (akm && bkm) hipLaunchKernelGGL((gemm_k<T, TO, BM, BN, true, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_k<T, TO, BM, BN, true, false>), grid, dim3(256), 0, st, p);
+    // FAST: every operand row is 16-byte aligned and its contiguous extent is a whole number of 16-byte vectors,
+    // and the output family can be accessed 4 elements at a time -> no scalar paths are compiled in
+    constexpr int EPV = 16 / (int)sizeof(T);
+    const long a_ext = akm ? p.M : p.K, b_ext = bkm ? p.N : p.K;
+    const bool fast = p.a_vec && p.b_vec && a_ext % EPV == 0 && b_ext % EPV == 0 && (p.partial || (p.o_vec && p.N % 4 == 0));
+    if (fast) launch_layout2<T, TO, BM, BN, true>(p, akm, bkm, grid, st);
+    else launch_layout2<T, TO, BM, BN, false>(p, akm, bkm, grid, st);
 }
 
 template <typename T, typename TO>
