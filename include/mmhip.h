@@ -133,6 +133,12 @@ int mm_prefix_attn_bwd(const void* q, const void* k, const void* v, const void* 
                        size_t workspace_bytes, int64_t B, int64_t H, int64_t S, int64_t d, int64_t rot,
                        int64_t prompt_len, int64_t ld_qkv, int64_t ld_dqkv, int mode, int dtype, void* stream);
 
+/* RoPE pre-pass (models/transformer_decoder.py:129-135 hoisted out of the attention kernel): rotates in place the
+ * first `rot` dims of every head of x [B][S][H][d] (row stride ld) at absolute position s; inverse=1 applies the
+ * transpose (gradients).  With q,k pre-rotated, call the attention entry points with rot = 0. */
+int mm_rope_inplace(void* x, const float* cos_t, const float* sin_t, int64_t B, int64_t S, int64_t H, int64_t d,
+                    int64_t rot, int64_t ld, int inverse, int dtype, void* stream);
+
 /* ---- K4: one decode step of attention against a KV cache ----------------------------------
  * no counterpart in the reference (it recomputes the full decoder every step,
  * train_autoregressive.py:97-101); equals row `pos` of K3 by the argument of SURVEY.md A9.

@@ -109,8 +109,7 @@ __global__ __launch_bounds__(256) void prefix_attn_fwd_k(const AttnP p) {
     for (int w = 0; w < 4; w++) {
         stage_rows<T, DP>(lk, PITCH, qg, p.ld, q0 + 16 * w, 16, p.S, p.d, p.vec_ok);
         __syncthreads();
-        rope_rows<T>(lk, PITCH, q0 + 16 * w, 16, p.S, p.rot, p.cos_t, p.sin_t, false);
-        __syncthreads();
+        if (p.rot > 0) { rope_rows<T>(lk, PITCH, q0 + 16 * w, 16, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if (wave == w) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ks++) {
@@ -140,8 +139,7 @@ __global__ __launch_bounds__(256) void prefix_attn_fwd_k(const AttnP p) {
         stage_rows<T, DP>(lk, PITCH, kg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
         stage_rows<T, DP>(lv, PITCH, vg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
         __syncthreads();
-        rope_rows<T>(lk, PITCH, k0, KT, p.S, p.rot, p.cos_t, p.sin_t, false);
-        __syncthreads();
+        if (p.rot > 0) { rope_rows<T>(lk, PITCH, k0, KT, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if (k0 < kend_w) {                           // wave-uniform
             if constexpr (BF) {
                 f32x4_t sacc[2];
@@ -393,8 +391,7 @@ __global__ __launch_bounds__(64) void prefix_attn_bwd_dq_k(const AttnP p) {
     stage_rows<T, DP>(lq, PITCH, qg, p.ld, q0, 16, p.S, p.d, p.vec_ok);
     stage_rows<T, DP>(ldo, PITCH, dog, p.ld_o, q0, 16, p.S, p.d, p.vec_ok);
     __syncthreads();
-    rope_rows<T>(lq, PITCH, q0, 16, p.S, p.rot, p.cos_t, p.sin_t, false);
-    __syncthreads();
+    if (p.rot > 0) { rope_rows<T>(lq, PITCH, q0, 16, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
     const int qi = q0 + fr;
     const bool qok = qi < p.S;
     const long stat = ((long)b * p.H + h) * p.S + (qok ? qi : 0);
@@ -412,8 +409,7 @@ __global__ __launch_bounds__(64) void prefix_attn_bwd_dq_k(const AttnP p) {
         stage_rows<T, DP>(lk, PITCH, kg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
         stage_rows<T, DP>(lv, PITCH, vg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
         __syncthreads();
-        rope_rows<T>(lk, PITCH, k0, KT, p.S, p.rot, p.cos_t, p.sin_t, false);
-        __syncthreads();
+        if (p.rot > 0) { rope_rows<T>(lk, PITCH, k0, KT, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if constexpr (BF) {
             f32x4_t sa[2], da[2];
 #pragma unroll
@@ -511,8 +507,7 @@ __global__ __launch_bounds__(64) void prefix_attn_bwd_dkv_k(const AttnP p) {
     stage_rows<T, DP>(lk, PITCH, kg, p.ld, kb0, 16, p.S, p.d, p.vec_ok);
     stage_rows<T, DP>(lv, PITCH, vg, p.ld, kb0, 16, p.S, p.d, p.vec_ok);
     __syncthreads();
-    rope_rows<T>(lk, PITCH, kb0, 16, p.S, p.rot, p.cos_t, p.sin_t, false);
-    __syncthreads();
+    if (p.rot > 0) { rope_rows<T>(lk, PITCH, kb0, 16, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
     const int kj = kb0 + fr;                         // this lane's key
     const long statbase = ((long)b * p.H + h) * p.S;
     // first query tile that can see any of these keys: prompt keys are seen by every query
@@ -531,8 +526,7 @@ __global__ __launch_bounds__(64) void prefix_attn_bwd_dkv_k(const AttnP p) {
             lstat[QT + lane] = qi < p.S ? p.delta[statbase + qi] : 0.f;
         }
         __syncthreads();
-        rope_rows<T>(lq, PITCH, q0, QT, p.S, p.rot, p.cos_t, p.sin_t, false);
-        __syncthreads();
+        if (p.rot > 0) { rope_rows<T>(lq, PITCH, q0, QT, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if constexpr (BF) {
             // S[query][key]: A = Q rows, B = K rows  -> lane = key, registers = 4 queries (x2 tiles)
             f32x4_t sa[2], da[2];
@@ -659,8 +653,7 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dq4_k(const AttnP p) {
         stage_rows<T, DP>(lk, PITCH, qg, p.ld, q0 + 16 * w, 16, p.S, p.d, p.vec_ok);
         stage_rows<T, DP>(lv, PITCH, dog, p.ld_o, q0 + 16 * w, 16, p.S, p.d, p.vec_ok);
         __syncthreads();
-        rope_rows<T>(lk, PITCH, q0 + 16 * w, 16, p.S, p.rot, p.cos_t, p.sin_t, false);
-        __syncthreads();
+        if (p.rot > 0) { rope_rows<T>(lk, PITCH, q0 + 16 * w, 16, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if (wave == w) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ks++) {
@@ -692,8 +685,7 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dq4_k(const AttnP p) {
         stage_rows<T, DP>(lk, PITCH, kg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
         stage_rows<T, DP>(lv, PITCH, vg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
         __syncthreads();
-        rope_rows<T>(lk, PITCH, k0, KT, p.S, p.rot, p.cos_t, p.sin_t, false);
-        __syncthreads();
+        if (p.rot > 0) { rope_rows<T>(lk, PITCH, k0, KT, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if (k0 < kend_w) {
             f32x4_t sa[2], da[2];
 #pragma unroll
@@ -773,8 +765,7 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dkv4_k(const AttnP p) {
         stage_rows<T, DP>(lq, PITCH, kg, p.ld, kb0 + 16 * w, 16, p.S, p.d, p.vec_ok);
         stage_rows<T, DP>(ldo, PITCH, vg, p.ld, kb0 + 16 * w, 16, p.S, p.d, p.vec_ok);
         __syncthreads();
-        rope_rows<T>(lq, PITCH, kb0 + 16 * w, 16, p.S, p.rot, p.cos_t, p.sin_t, false);
-        __syncthreads();
+        if (p.rot > 0) { rope_rows<T>(lq, PITCH, kb0 + 16 * w, 16, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if (wave == w) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ks++) {
@@ -804,8 +795,7 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dkv4_k(const AttnP p) {
             lstat[QT + tid] = qi < p.S ? p.delta[statbase + qi] : 0.f;
         }
         __syncthreads();
-        rope_rows<T>(lq, PITCH, q0, QT, p.S, p.rot, p.cos_t, p.sin_t, false);
-        __syncthreads();
+        if (p.rot > 0) { rope_rows<T>(lq, PITCH, q0, QT, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if (wave_live && q0 + QT > qstart_w) {
             f32x4_t sa[2], da[2];
 #pragma unroll
@@ -1191,6 +1181,43 @@ extern "C" int mm_decode_attn(const void* q, const void* k_new, const void* v_ne
         else MM_FAIL(MM_ERR_UNSUPPORTED, "decode_attn: head_dim %lld must be a multiple of 4", (long long)d);
     } else MM_FAIL(MM_ERR_ARG, "decode_attn: bad dtype %d", dtype);
 #undef L_
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE pre-pass: rotate (or un-rotate, inverse=1) the first `rot` dims of every head of x [B][S][H][d] in place.
+// Lets the attention kernels run with rot = 0: q,k are rotated ONCE per layer instead of once per tile,
+// and the backward un-rotates dq,dk once.  HBM traffic: 2 * B*S*H*rot elements.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rope_inplace_k(T* __restrict__ x, const float* __restrict__ cos_t, const float* __restrict__ sin_t, long total,
+                               int S, int H, int d, int half, long ld, int inverse) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int i = (int)(idx % half);
+    const int h = (int)((idx / half) % H);
+    const long bs = idx / ((long)half * H);
+    const int s = (int)(bs % S);
+    T* row = x + bs * ld + (long)h * d;
+    const float c = cos_t[(long)s * half + i];
+    float sn = sin_t[(long)s * half + i];
+    if (inverse) sn = -sn;
+    const float a = to_f(row[i]), b = to_f(row[i + half]);
+    row[i] = from_f<T>(a * c - b * sn);
+    row[i + half] = from_f<T>(b * c + a * sn);
+}
+extern "C" int mm_rope_inplace(void* x, const float* cos_t, const float* sin_t, int64_t B, int64_t S, int64_t H, int64_t d,
+                               int64_t rot, int64_t ld, int inverse, int dtype, void* stream) {
+    MM_CHECK(x && cos_t && sin_t, "rope_inplace: null pointer");
+    MM_CHECK(B > 0 && S > 0 && H > 0 && d > 0 && rot > 0 && rot <= d && rot % 2 == 0 && ld >= H * d, "rope_inplace: bad shape");
+    const int half = (int)(rot / 2);
+    const long total = B * S * H * half;
+    const dim3 grid((unsigned)cdiv(total, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MM_BF16) hipLaunchKernelGGL(rope_inplace_k<bf16>, grid, dim3(256), 0, st, (bf16*)x, cos_t, sin_t, total, (int)S, (int)H, (int)d, half, (long)ld, inverse);
+    else if (dtype == MM_F32) hipLaunchKernelGGL(rope_inplace_k<float>, grid, dim3(256), 0, st, (float*)x, cos_t, sin_t, total, (int)S, (int)H, (int)d, half, (long)ld, inverse);
+    else MM_FAIL(MM_ERR_ARG, "rope_inplace: bad dtype %d", dtype);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }

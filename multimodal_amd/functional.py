@@ -186,7 +186,10 @@ class PrefixAttention(torch.autograd.Function):
     def forward(ctx, qkv, cos_t, sin_t, H, rot, prompt_len, stablemax):
         train = ctx.needs_input_grad[0]
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-        o, lse = ops.prefix_attn_fwd(q, k, v, H, rot, prompt_len, cos_t, sin_t, stablemax, save_lse=train)
+        # q,k are rotated ONCE, in place (qkv is the projection's own output; nothing else reads it un-rotated)
+        ops.rope_inplace(q, H, rot, cos_t, sin_t)
+        ops.rope_inplace(k, H, rot, cos_t, sin_t)
+        o, lse = ops.prefix_attn_fwd(q, k, v, H, 0, prompt_len, cos_t, sin_t, stablemax, save_lse=train)
         if train:
             ctx.save_for_backward(qkv, o, lse, cos_t, sin_t)
             ctx.cfg = (H, rot, prompt_len, stablemax)
@@ -196,6 +199,8 @@ class PrefixAttention(torch.autograd.Function):
     def backward(ctx, d_o):
         qkv, o, lse, cos_t, sin_t = ctx.saved_tensors
         H, rot, prompt_len, stablemax = ctx.cfg
-        dqkv = ops.prefix_attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, d_o.contiguous(), lse, H, rot, prompt_len,
-                                   cos_t, sin_t, stablemax)
+        dqkv = ops.prefix_attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, d_o.contiguous(), lse, H, 0, prompt_len,
+                                   cos_t, sin_t, stablemax)          # saved q,k are already rotated
+        ops.rope_inplace(dqkv[:, :, 0], H, rot, cos_t, sin_t, inverse=True)
+        ops.rope_inplace(dqkv[:, :, 1], H, rot, cos_t, sin_t, inverse=True)
         return dqkv, None, None, None, None, None, None

@@ -326,3 +326,14 @@ def argmax_rows(logits: Tensor) -> Tensor:
     L.check(L.lib().mm_argmax_rows(L.ptr(logits), L.ptr(out), logits.shape[0], logits.shape[1], logits.stride(0),
                                    L.dtype_code(logits), L.cur_stream()), "mm_argmax_rows")
     return out
+
+
+def rope_inplace(x: Tensor, H: int, rot: int, cos_t: Tensor, sin_t: Tensor, inverse: bool = False) -> None:
+    """x: [B,S,E] view (unit inner stride, batch stride S*row stride), rotated in place."""
+    if rot == 0:
+        return
+    B, S, E = x.shape
+    if not x.is_cuda or x.stride(2) != 1 or (B > 1 and x.stride(0) != S * x.stride(1)):
+        raise RuntimeError("rope_inplace: expected a GPU [B,S,E] view with unit inner stride")
+    L.check(L.lib().mm_rope_inplace(L.ptr(x), L.ptr(cos_t), L.ptr(sin_t), B, S, H, E // H, rot, x.stride(1), int(inverse),
+                                    L.dtype_code(x), L.cur_stream()), "mm_rope_inplace")
