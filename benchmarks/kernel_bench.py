@@ -72,7 +72,12 @@ if __name__ == "__main__":
     ap.add_argument("--what", default="k1,gemm")
     a = ap.parse_args()
     res = []
-    if "k1" in a.what:
+    if "quick1" in a.what:
+        for dt in (torch.float32, torch.bfloat16):
+            for (B, C, Ln) in [(8192, 64, 250), (8192, 256, 62), (2048, 1600, 31)]:
+                res.append(bench_k1(B, C, Ln, dt)); print(json.dumps(res[-1]), flush=True)
+            res.append(bench_k1(8192, 64, 250, dt, bwd=True)); print(json.dumps(res[-1]), flush=True)
+    if "k1" in a.what.split(","):
         for dt in (torch.float32, torch.bfloat16):
             for (B, C, Ln) in [(8192, 64, 250), (8192, 128, 125), (8192, 256, 62), (4096, 1600, 31), (32, 64, 250), (32, 256, 62), (32, 1600, 31)]:
                 res.append(bench_k1(B, C, Ln, dt)); print(json.dumps(res[-1]), flush=True)

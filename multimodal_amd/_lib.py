@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmmhip.so")
+LIB_PATH = os.environ.get("MM_LIB") or os.path.join(_HERE, "lib", "libmmhip.so")   # MM_LIB: kernel A/B experiments
 
 MM_F32, MM_BF16 = 0, 1
 LAYOUT_BLC, LAYOUT_BCL = 0, 1

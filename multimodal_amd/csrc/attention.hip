@@ -27,32 +27,47 @@ template <typename T> struct AT;
 template <> struct AT<bf16> { static constexpr int KT = 32, PAD = 8, KSTEP = 32; };
 template <> struct AT<float> { static constexpr int KT = 16, PAD = 2, KSTEP = 4; };
 
-// stage `nrows` rows (row0..) of a [S][d] head slice into LDS [nrows][pitch], zero padded to DP columns
-template <typename T, int DP>
-__device__ __forceinline__ void stage_rows(T* lds, int pitch, const T* __restrict__ g, long ld, int row0, int nrows,
+// stage NROWS rows (row0..) of a [S][d] head slice into LDS [NROWS][pitch], zero padded to DP columns.
+// Two phases -- all global loads first (up to 8 vectors per thread in flight), then the LDS writes -- so the
+// load latencies overlap instead of serialising (the one-phase loop cost ~1 us per vector).
+template <typename T, int DP, int NROWS, int NT>
+__device__ __forceinline__ void stage_rows(T* lds, int pitch, const T* __restrict__ g, long ld, int row0,
                                            int S, int d, bool vec_ok) {
-    constexpr int V4 = DP / 4;
-    for (int idx = threadIdx.x; idx < nrows * V4; idx += blockDim.x) {
-        const int r = idx / V4, c = (idx % V4) * 4;
-        const int row = row0 + r;
-        alignas(16) T v[4];
-        if (row < S && c < d) {
-            const T* src = g + (long)row * ld + c;
-            if (vec_ok && c + 4 <= d) {
-                if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(v) = *reinterpret_cast<const uint2*>(src);
-                else *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(src);
+    constexpr int V4 = DP / 4, TOT = NROWS * V4, IT = (TOT + NT - 1) / NT;
+    constexpr int CH = IT < 8 ? IT : 8;
+    struct alignas(16) Vec { T e[4]; };
+    for (int it0 = 0; it0 < IT; it0 += CH) {
+        Vec v[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const int idx = threadIdx.x + (it0 + j) * NT;
+            const int r = idx / V4, c = (idx % V4) * 4;
+            const int row = row0 + r;
+            if (idx < TOT && row < S && c < d) {
+                const T* src = g + (long)row * ld + c;
+                if (vec_ok && c + 4 <= d) {
+                    if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(v[j].e) = *reinterpret_cast<const uint2*>(src);
+                    else *reinterpret_cast<float4*>(v[j].e) = *reinterpret_cast<const float4*>(src);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[j].e[q] = (c + q < d) ? src[q] : T(0.0f);
+                }
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++) v[j] = (c + j < d) ? src[j] : T(0.0f);
+                for (int q = 0; q < 4; q++) v[j].e[q] = T(0.0f);
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = T(0.0f);
         }
-        if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(&lds[r * pitch + c]) = *reinterpret_cast<uint2*>(v);
-        else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) lds[r * pitch + c + j] = v[j];
+        for (int j = 0; j < CH; j++) {
+            const int idx = threadIdx.x + (it0 + j) * NT;
+            if (idx < TOT) {
+                const int r = idx / V4, c = (idx % V4) * 4;
+                if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(&lds[r * pitch + c]) = *reinterpret_cast<uint2*>(v[j].e);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) lds[r * pitch + c + q] = v[j].e[q];
+                }
+            }
         }
     }
 }
@@ -107,7 +122,7 @@ __global__ __launch_bounds__(256) void prefix_attn_fwd_k(const AttnP p) {
     typedef typename std::conditional<BF, bf16x8_t, float>::type Frag;
     Frag qf[NKS];
     for (int w = 0; w < 4; w++) {
-        stage_rows<T, DP>(lk, PITCH, qg, p.ld, q0 + 16 * w, 16, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, 16, 256>(lk, PITCH, qg, p.ld, q0 + 16 * w, p.S, p.d, p.vec_ok);
         __syncthreads();
         if (p.rot > 0) { rope_rows<T>(lk, PITCH, q0 + 16 * w, 16, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if (wave == w) {
@@ -136,8 +151,8 @@ __global__ __launch_bounds__(256) void prefix_attn_fwd_k(const AttnP p) {
     float m_run = -INFINITY, l_run = 0.f;
 
     for (int k0 = 0; k0 < kend_blk; k0 += KT) {
-        stage_rows<T, DP>(lk, PITCH, kg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
-        stage_rows<T, DP>(lv, PITCH, vg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, KT, 256>(lk, PITCH, kg, p.ld, k0, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, KT, 256>(lv, PITCH, vg, p.ld, k0, p.S, p.d, p.vec_ok);
         __syncthreads();
         if (p.rot > 0) { rope_rows<T>(lk, PITCH, k0, KT, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if (k0 < kend_w) {                           // wave-uniform
@@ -388,8 +403,8 @@ __global__ __launch_bounds__(64) void prefix_attn_bwd_dq_k(const AttnP p) {
     const T* kg = (const T*)p.k + head_off;
     const T* vg = (const T*)p.v + head_off;
     const T* dog = (const T*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d;
-    stage_rows<T, DP>(lq, PITCH, qg, p.ld, q0, 16, p.S, p.d, p.vec_ok);
-    stage_rows<T, DP>(ldo, PITCH, dog, p.ld_o, q0, 16, p.S, p.d, p.vec_ok);
+    stage_rows<T, DP, 16, 64>(lq, PITCH, qg, p.ld, q0, p.S, p.d, p.vec_ok);
+    stage_rows<T, DP, 16, 64>(ldo, PITCH, dog, p.ld_o, q0, p.S, p.d, p.vec_ok);
     __syncthreads();
     if (p.rot > 0) { rope_rows<T>(lq, PITCH, q0, 16, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
     const int qi = q0 + fr;
@@ -406,8 +421,8 @@ __global__ __launch_bounds__(64) void prefix_attn_bwd_dq_k(const AttnP p) {
     for (int n = 0; n < NDV; n++) dqa[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     for (int k0 = 0; k0 < kend; k0 += KT) {
-        stage_rows<T, DP>(lk, PITCH, kg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
-        stage_rows<T, DP>(lv, PITCH, vg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, KT, 64>(lk, PITCH, kg, p.ld, k0, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, KT, 64>(lv, PITCH, vg, p.ld, k0, p.S, p.d, p.vec_ok);
         __syncthreads();
         if (p.rot > 0) { rope_rows<T>(lk, PITCH, k0, KT, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if constexpr (BF) {
@@ -504,8 +519,8 @@ __global__ __launch_bounds__(64) void prefix_attn_bwd_dkv_k(const AttnP p) {
     const T* kg = (const T*)p.k + head_off;
     const T* vg = (const T*)p.v + head_off;
     const T* dog = (const T*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d;
-    stage_rows<T, DP>(lk, PITCH, kg, p.ld, kb0, 16, p.S, p.d, p.vec_ok);
-    stage_rows<T, DP>(lv, PITCH, vg, p.ld, kb0, 16, p.S, p.d, p.vec_ok);
+    stage_rows<T, DP, 16, 64>(lk, PITCH, kg, p.ld, kb0, p.S, p.d, p.vec_ok);
+    stage_rows<T, DP, 16, 64>(lv, PITCH, vg, p.ld, kb0, p.S, p.d, p.vec_ok);
     __syncthreads();
     if (p.rot > 0) { rope_rows<T>(lk, PITCH, kb0, 16, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
     const int kj = kb0 + fr;                         // this lane's key
@@ -518,8 +533,8 @@ __global__ __launch_bounds__(64) void prefix_attn_bwd_dkv_k(const AttnP p) {
     for (int n = 0; n < NDV; n++) { dka[n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dva[n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 
     for (int q0 = qstart; q0 < p.S; q0 += QT) {
-        stage_rows<T, DP>(lq, PITCH, qg, p.ld, q0, QT, p.S, p.d, p.vec_ok);
-        stage_rows<T, DP>(ldo, PITCH, dog, p.ld_o, q0, QT, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, QT, 64>(lq, PITCH, qg, p.ld, q0, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, QT, 64>(ldo, PITCH, dog, p.ld_o, q0, p.S, p.d, p.vec_ok);
         if (lane < QT) {
             const int qi = q0 + lane;
             lstat[lane] = qi < p.S ? p.lse[statbase + qi] : 1.f;
@@ -650,8 +665,8 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dq4_k(const AttnP p) {
     const T* dog = (const T*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d;
     bf16x8_t qf[NKS], gf[NKS];
     for (int w = 0; w < 4; w++) {
-        stage_rows<T, DP>(lk, PITCH, qg, p.ld, q0 + 16 * w, 16, p.S, p.d, p.vec_ok);
-        stage_rows<T, DP>(lv, PITCH, dog, p.ld_o, q0 + 16 * w, 16, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, 16, 256>(lk, PITCH, qg, p.ld, q0 + 16 * w, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, 16, 256>(lv, PITCH, dog, p.ld_o, q0 + 16 * w, p.S, p.d, p.vec_ok);
         __syncthreads();
         if (p.rot > 0) { rope_rows<T>(lk, PITCH, q0 + 16 * w, 16, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if (wave == w) {
@@ -682,8 +697,8 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dq4_k(const AttnP p) {
     for (int n = 0; n < NDV; n++) dqa[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     for (int k0 = 0; k0 < kend_blk; k0 += KT) {
-        stage_rows<T, DP>(lk, PITCH, kg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
-        stage_rows<T, DP>(lv, PITCH, vg, p.ld, k0, KT, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, KT, 256>(lk, PITCH, kg, p.ld, k0, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, KT, 256>(lv, PITCH, vg, p.ld, k0, p.S, p.d, p.vec_ok);
         __syncthreads();
         if (p.rot > 0) { rope_rows<T>(lk, PITCH, k0, KT, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if (k0 < kend_w) {
@@ -762,8 +777,8 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dkv4_k(const AttnP p) {
     const T* dog = (const T*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d;
     bf16x8_t kf[NKS], vf[NKS];
     for (int w = 0; w < 4; w++) {
-        stage_rows<T, DP>(lq, PITCH, kg, p.ld, kb0 + 16 * w, 16, p.S, p.d, p.vec_ok);
-        stage_rows<T, DP>(ldo, PITCH, vg, p.ld, kb0 + 16 * w, 16, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, 16, 256>(lq, PITCH, kg, p.ld, kb0 + 16 * w, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, 16, 256>(ldo, PITCH, vg, p.ld, kb0 + 16 * w, p.S, p.d, p.vec_ok);
         __syncthreads();
         if (p.rot > 0) { rope_rows<T>(lq, PITCH, kb0 + 16 * w, 16, p.S, p.rot, p.cos_t, p.sin_t, false); __syncthreads(); }
         if (wave == w) {
@@ -787,8 +802,8 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dkv4_k(const AttnP p) {
     for (int n = 0; n < NDV; n++) { dka[n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dva[n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 
     for (int q0 = qstart_blk; q0 < p.S; q0 += QT) {
-        stage_rows<T, DP>(lq, PITCH, qg, p.ld, q0, QT, p.S, p.d, p.vec_ok);
-        stage_rows<T, DP>(ldo, PITCH, dog, p.ld_o, q0, QT, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, QT, 256>(lq, PITCH, qg, p.ld, q0, p.S, p.d, p.vec_ok);
+        stage_rows<T, DP, QT, 256>(ldo, PITCH, dog, p.ld_o, q0, p.S, p.d, p.vec_ok);
         if (tid < QT) {
             const int qi = q0 + tid;
             lstat[tid] = qi < p.S ? p.lse[statbase + qi] : 1.f;

@@ -36,11 +36,20 @@ template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return __flo
 
 // ---------------------------------------------------------------- vector load/store of VEC elements -> float[VEC]
 template <typename T, int VEC> struct VecIO;
+typedef __attribute__((ext_vector_type(4))) float mm_f4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned mm_u4_t;
 template <> struct VecIO<float, 4> {
     static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
         float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    // non-temporal forms for once-touched streams (measured on K1: +4% fwd stores, +10% bwd loads)
+    static __device__ __forceinline__ void load_nt(const float* p, float (&v)[4]) {
+        mm_f4_t t = __builtin_nontemporal_load(reinterpret_cast<const mm_f4_t*>(p));
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    static __device__ __forceinline__ void store_nt(float* p, const float (&v)[4]) {
+        mm_f4_t t = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<mm_f4_t*>(p)); }
 };
 template <> struct VecIO<float, 2> {
     static __device__ __forceinline__ void load(const float* p, float (&v)[2]) {
@@ -65,6 +74,8 @@ template <> struct VecIO<bf16, 8> {
         for (int i = 0; i < 4; i++) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    static __device__ __forceinline__ void load_nt(const bf16* p, float (&v)[8]) { load(p, v); }
+    static __device__ __forceinline__ void store_nt(bf16* p, const float (&v)[8]) { store(p, v); }
 };
 template <> struct VecIO<bf16, 4> {
     static __device__ __forceinline__ void load(const bf16* p, float (&v)[4]) {
@@ -78,6 +89,8 @@ template <> struct VecIO<bf16, 4> {
         t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
         *reinterpret_cast<uint2*>(p) = t;
     }
+    static __device__ __forceinline__ void load_nt(const bf16* p, float (&v)[4]) { load(p, v); }
+    static __device__ __forceinline__ void store_nt(bf16* p, const float (&v)[4]) { store(p, v); }
 };
 template <> struct VecIO<bf16, 2> {
     static __device__ __forceinline__ void load(const bf16* p, float (&v)[2]) {

@@ -11,8 +11,14 @@
 // "wide" kernels (any C): one 256-thread workgroup per strip, channels spread over the block,
 // cross-wave sums through LDS.
 #include "common.h"
+#include <stdlib.h>
 
-#define RING 8          // 7 taps + 1 row of prefetch; power of two so the unrolled slot indices are static
+#ifndef RINGB
+#define RINGB 8
+#endif
+#ifndef RINGF
+#define RINGF 8          // 7 taps + (RINGF-7) rows of prefetch; the walk is unrolled RINGF times so slot indices are static
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // forward, channels-last input, strip kernel
@@ -46,7 +52,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_fwd_strip(const T* __restrict_
         for (int t = 0; t < 7; t++) wt[t][v] = w[(c0 + v) * 7 + t];
         bias[v] = cb[c0 + v]; g[v] = lw[c0 + v]; be[v] = lb[c0 + v];
     }
-    float win[RING][VEC];
+    float win[RINGF][VEC];
     auto load_row = [&](int l, float (&dst)[VEC]) {
         if (l >= 0 && l < L) VecIO<T, VEC>::load(xb + (long)l * C, dst);
         else {
@@ -55,21 +61,21 @@ __global__ __launch_bounds__(256) void dwconv7_ln_fwd_strip(const T* __restrict_
         }
     };
 #pragma unroll
-    for (int s = 0; s < RING - 1; s++) load_row(l0 - 3 + s, win[s]);      // rows l0-3 .. l0+3
+    for (int s = 0; s < RINGF - 1; s++) load_row(l0 - 3 + s, win[s]);      // rows l0-3 .. l0+RINGF-5
 
     const float invC = 1.0f / (float)C;
-    for (int base = l0; base < l1; base += RING) {
+    for (int base = l0; base < l1; base += RINGF) {
 #pragma unroll
-        for (int i = 0; i < RING; i++) {
+        for (int i = 0; i < RINGF; i++) {
             const int l = base + i;
-            load_row(l + 4, win[(i + 7) % RING]);                          // prefetch one row ahead
+            load_row(l + RINGF - 4, win[(i + RINGF - 1) % RINGF]);            // prefetch RINGF-7 rows ahead
             float acc[VEC];
             float s1 = 0.f;
 #pragma unroll
             for (int v = 0; v < VEC; v++) {
                 float a = bias[v];
 #pragma unroll
-                for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], win[(i + t) % RING][v], a);
+                for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], win[(i + t) % RINGF][v], a);
                 acc[v] = a; s1 += a;
             }
             const float mu = group_sum<LPR>(s1) * invC;
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_fwd_strip(const T* __restrict_
                 float o[VEC];
 #pragma unroll
                 for (int v = 0; v < VEC; v++) o[v] = fmaf(acc[v] * rs, g[v], be[v]);
-                VecIO<T, VEC>::store(yb + (long)l * C, o);
+                VecIO<T, VEC>::store_nt(yb + (long)l * C, o);
                 if (mean_out && li == 0) { mean_out[(long)b * L + l] = mu; rstd_out[(long)b * L + l] = rs; }
             }
         }
@@ -265,9 +271,9 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
         for (int t = 0; t < 7; t++) pdw[t][v] = 0.f;
         pdb[v] = 0.f; pdg[v] = 0.f; pdbeta[v] = 0.f;
     }
-    float xw[RING][VEC], dc[RING][VEC];
+    float xw[RINGB][VEC], dc[RINGB][VEC];
     auto load_x = [&](int l, float (&dst)[VEC]) {
-        if (l >= 0 && l < L) VecIO<T, VEC>::load(xb + (long)l * C, dst);
+        if (l >= 0 && l < L) VecIO<T, VEC>::load_nt(xb + (long)l * C, dst);
         else {
 #pragma unroll
             for (int v = 0; v < VEC; v++) dst[v] = 0.f;
@@ -275,26 +281,26 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
     };
     // the walk starts at l = l0-3: x ring slots 0..6 hold rows l0-6 .. l0
 #pragma unroll
-    for (int s = 0; s < RING - 1; s++) load_x(l0 - 6 + s, xw[s]);
+    for (int s = 0; s < RINGB - 1; s++) load_x(l0 - 6 + s, xw[s]);
 #pragma unroll
-    for (int s = 0; s < RING; s++)
+    for (int s = 0; s < RINGB; s++)
 #pragma unroll
         for (int v = 0; v < VEC; v++) dc[s][v] = 0.f;
 
     const float invC = 1.0f / (float)C;
     const int lend = l1 + 3;
-    for (int base = l0 - 3; base < lend; base += RING) {
+    for (int base = l0 - 3; base < lend; base += RINGB) {
 #pragma unroll
-        for (int i = 0; i < RING; i++) {
+        for (int i = 0; i < RINGB; i++) {
             const int l = base + i;                         // row whose dconv is produced now
-            load_x(l + 4, xw[(i + 7) % RING]);              // prefetch (row l+3 was loaded last step)
+            load_x(l + RINGB - 4, xw[(i + RINGB - 1) % RINGB]);   // prefetch RINGB-7 rows ahead
             const bool inrow = (l >= 0 && l < L && l < lend);
             // rows outside the image are computed on zeros (mu = rs = 0 -> dconv = 0): control flow stays
             // uniform, so the DPP sums always run with full EXEC
             float gy[VEC], xh[VEC], gg[VEC], d[VEC];
             float mu = 0.f, rs = 0.f;
             if (inrow) {
-                VecIO<T, VEC>::load(dyb + (long)l * C, gy);
+                VecIO<T, VEC>::load_nt(dyb + (long)l * C, gy);
                 mu = mean[rowbase + l]; rs = rstd[rowbase + l];
             } else {
 #pragma unroll
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
             for (int v = 0; v < VEC; v++) {
                 float a = bias[v];
 #pragma unroll
-                for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], xw[(i + t) % RING][v], a);
+                for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], xw[(i + t) % RINGB][v], a);
                 xh[v] = (a - mu) * rs;
                 gg[v] = gy[v] * g[v];
                 s1 += gg[v]; s2 = fmaf(gg[v], xh[v], s2);
@@ -321,16 +327,16 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
                     pdbeta[v] += gy[v];
                     pdb[v] += d[v];
 #pragma unroll
-                    for (int t = 0; t < 7; t++) pdw[t][v] = fmaf(d[v], xw[(i + t) % RING][v], pdw[t][v]);
+                    for (int t = 0; t < 7; t++) pdw[t][v] = fmaf(d[v], xw[(i + t) % RINGB][v], pdw[t][v]);
                 }
             }
 #pragma unroll
-            for (int v = 0; v < VEC; v++) dc[i][v] = d[v];  // dconv ring slot of row l is i (RING == unroll)
+            for (int v = 0; v < VEC; v++) dc[i][v] = d[v];  // dconv ring slot of row l is i (RINGB == unroll)
             // dx(l-3) = sum_t w[t] * dconv(l-3-t+3) = sum_t w[t] * dconv(l-t)
             const int lo = l - 3;
             if (live && lo >= l0 && lo < l1) {
                 float o[VEC];
-                if (dres) VecIO<T, VEC>::load(dres + (rowbase + lo) * C + c0, o);
+                if (dres) VecIO<T, VEC>::load_nt(dres + (rowbase + lo) * C + c0, o);
                 else {
 #pragma unroll
                     for (int v = 0; v < VEC; v++) o[v] = 0.f;
@@ -339,10 +345,10 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
                 for (int v = 0; v < VEC; v++) {
                     float a = o[v];
 #pragma unroll
-                    for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], dc[(i - t + RING) % RING][v], a);
+                    for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], dc[(i - t + RINGB) % RINGB][v], a);
                     o[v] = a;
                 }
-                VecIO<T, VEC>::store(dxb + (long)lo * C, o);
+                VecIO<T, VEC>::store_nt(dxb + (long)lo * C, o);
             }
         }
     }
@@ -526,7 +532,8 @@ static int launch_fwd_strip(const void* x, const float* w, const float* b, const
                             float* mean, float* rstd, int64_t B, int64_t C, int64_t L, float eps, hipStream_t st) {
     const int lpr = (int)(C / VEC);
     const int spw = 64 / lpr;
-    const int TL = pick_tl(B, L, spw, 4, 64);
+    static int tlmax = getenv("MM_K1_TLMAX") ? atoi(getenv("MM_K1_TLMAX")) : 64;
+    const int TL = pick_tl(B, L, spw, 4, tlmax);
     const int sps = (int)cdiv(L, TL);
     const int64_t waves = cdiv(B * sps, spw);
     const dim3 grid((unsigned)cdiv(waves, 4));
