@@ -58,10 +58,11 @@ def bench_attn(B, H, d, S, P, dtype, stablemax=True):
     inv = 1.0 / (10000 ** (torch.arange(0, rot, 2, device=dev).float() / rot))
     cos_t, sin_t = ops.rope_tables(inv, S)
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-    o, lse = ops.prefix_attn_fwd(q, k, v, H, rot, P, cos_t, sin_t, stablemax, save_lse=True)
+    ops.rope_inplace(q, H, rot, cos_t, sin_t); ops.rope_inplace(k, H, rot, cos_t, sin_t)   # as the model does
+    o, lse = ops.prefix_attn_fwd(q, k, v, H, 0, P, cos_t, sin_t, stablemax, save_lse=True)
     do = torch.randn_like(o)
-    tf = timeit(lambda: ops.prefix_attn_fwd(q, k, v, H, rot, P, cos_t, sin_t, stablemax, save_lse=True))
-    tb = timeit(lambda: ops.prefix_attn_bwd(q, k, v, o, do, lse, H, rot, P, cos_t, sin_t, stablemax))
+    tf = timeit(lambda: ops.prefix_attn_fwd(q, k, v, H, 0, P, cos_t, sin_t, stablemax, save_lse=True))
+    tb = timeit(lambda: ops.prefix_attn_bwd(q, k, v, o, do, lse, H, 0, P, cos_t, sin_t, stablemax))
     fl = 4.0 * B * S * S * E
     return dict(kernel="prefix_attn", B=B, H=H, d=d, S=S, P=P, dtype=str(dtype), stablemax=stablemax, fwd_us=tf * 1e6,
                 bwd_us=tb * 1e6, fwd_TFLOPs=fl / tf / 1e12, bwd_TFLOPs=2.5 * fl / tb / 1e12)

@@ -12,6 +12,7 @@
 // [S,S] score tensor ever exists in HBM (the reference materialises ~7 of them).
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 struct AttnP {
     const void* q; const void* k; const void* v; void* o; float* lse;
@@ -259,6 +260,193 @@ __global__ __launch_bounds__(256) void prefix_attn_fwd_k(const AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 fast path (q,k already rotated by mm_rope_inplace, 8-byte aligned rows): Q fragments come straight
+// from global memory (no LDS round trips in the prologue), key tiles are KT = 64 (32 for d > 256) keys, and
+// the next tile's global loads are issued BEFORE the current tile is multiplied (register prefetch), so a
+// tile costs one barrier pair and no exposed load latency.
+// ------------------------------------------------------------------------------------------------
+template <int DP, int NROWS>
+struct TileRegs { static constexpr int IT = NROWS * (DP / 4) / 256; uint2 v[IT]; };
+
+template <int DP, int NROWS>
+__device__ __forceinline__ void tile_load(TileRegs<DP, NROWS>& r, const bf16* __restrict__ g, long ld, int row0, int S, int d) {
+    constexpr int V4 = DP / 4;
+#pragma unroll
+    for (int j = 0; j < TileRegs<DP, NROWS>::IT; j++) {
+        const int idx = threadIdx.x + j * 256;
+        const int rr = idx / V4, c = (idx % V4) * 4;
+        const int row = row0 + rr;
+        if (row < S && c < d) r.v[j] = *reinterpret_cast<const uint2*>(g + (long)row * ld + c);
+        else r.v[j] = make_uint2(0u, 0u);
+    }
+}
+template <int DP, int NROWS>
+__device__ __forceinline__ void tile_store(const TileRegs<DP, NROWS>& r, bf16* lds, int pitch) {
+    constexpr int V4 = DP / 4;
+#pragma unroll
+    for (int j = 0; j < TileRegs<DP, NROWS>::IT; j++) {
+        const int idx = threadIdx.x + j * 256;
+        const int rr = idx / V4, c = (idx % V4) * 4;
+        *reinterpret_cast<uint2*>(&lds[rr * pitch + c]) = r.v[j];
+    }
+}
+// 8 consecutive bf16 of one row as an MFMA fragment, straight from global (two 8-byte loads; zero beyond d / S)
+__device__ __forceinline__ bf16x8_t frag_load(const bf16* __restrict__ g, long ld, int row, int col, int S, int d) {
+    uint2 a = make_uint2(0u, 0u), b = make_uint2(0u, 0u);
+    if (row < S) {
+        const bf16* src = g + (long)row * ld + col;
+        if (col < d) a = *reinterpret_cast<const uint2*>(src);
+        if (col + 4 < d) b = *reinterpret_cast<const uint2*>(src + 4);
+    }
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    const u4 w = {a.x, a.y, b.x, b.y};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+
+template <int DP, int KT, bool STABLE>
+__global__ __launch_bounds__(256) void prefix_attn_fwd2_k(const AttnP p) {
+    typedef bf16 T;
+    constexpr int PITCH = DP + 8;
+    constexpr int NKS = DP / 32, NDV = DP / 16, NT16 = KT / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* lk = reinterpret_cast<T*>(smem);
+    T* lv = lk + KT * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = blockIdx.x * 64;
+    const long head_off = (long)b * p.S * p.ld + (long)h * p.d;
+    const T* qg = (const T*)p.q + head_off;
+    const T* kg = (const T*)p.k + head_off;
+    const T* vg = (const T*)p.v + head_off;
+    const int qw0 = q0 + 16 * wave;
+    const int qi = qw0 + fr;
+    auto key_end = [&](int qlo, int qhi) {
+        int e = min(qhi, p.S - 1) + 1;
+        if (qlo < p.P) e = max(e, p.P);
+        return min(e, p.S);
+    };
+    const int kend_blk = key_end(q0, q0 + 63);
+    const int kend_w = (qw0 < p.S) ? key_end(qw0, qw0 + 15) : 0;
+
+    TileRegs<DP, KT> rk, rv;
+    tile_load<DP, KT>(rk, kg, p.ld, 0, p.S, p.d);
+    tile_load<DP, KT>(rv, vg, p.ld, 0, p.S, p.d);
+    bf16x8_t qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) qf[ks] = frag_load(qg, p.ld, qi, ks * 32 + fg * 8, p.S, p.d);
+
+    f32x4_t oacc[NDV];
+#pragma unroll
+    for (int n = 0; n < NDV; n++) oacc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    typedef bf16x4_t __attribute__((address_space(3))) * lds4p;
+    const int qq = fr >> 2, pp = fr & 3;
+
+    for (int k0 = 0; k0 < kend_blk; k0 += KT) {
+        tile_store<DP, KT>(rk, lk, PITCH);
+        tile_store<DP, KT>(rv, lv, PITCH);
+        __syncthreads();
+        if (k0 + KT < kend_blk) {                       // prefetch: in flight while this tile is multiplied
+            tile_load<DP, KT>(rk, kg, p.ld, k0 + KT, p.S, p.d);
+            tile_load<DP, KT>(rv, vg, p.ld, k0 + KT, p.S, p.d);
+        }
+        if (k0 < kend_w) {
+            f32x4_t sacc[NT16];
+#pragma unroll
+            for (int t = 0; t < NT16; t++) {
+                sacc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ks++) {
+                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&lk[(16 * t + fr) * PITCH + ks * 32 + fg * 8]);
+                    sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sacc[t], 0, 0, 0);
+                }
+            }
+            float pv[4 * NT16];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < NT16; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int kj = k0 + 16 * t + 4 * fg + r;
+                    const float x = sacc[t][r] * p.scale;
+                    const bool ok = attn_allowed(qi, kj, p.P, p.S);
+                    if (STABLE) pv[4 * t + r] = ok ? stable_s_f(x) : 0.f;
+                    else { pv[4 * t + r] = ok ? x : -INFINITY; tmax = fmaxf(tmax, pv[4 * t + r]); }
+                }
+            if (!STABLE) {
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int n = 0; n < NDV; n++) oacc[n] *= alpha;
+#pragma unroll
+                for (int e = 0; e < 4 * NT16; e++) pv[e] = (m_new == -INFINITY) ? 0.f : __expf(pv[e] - m_new);
+                m_run = m_new;
+            }
+#pragma unroll
+            for (int kk = 0; kk < KT / 32; kk++) {
+                bf16x8_t pf;
+#pragma unroll
+                for (int e = 0; e < 8; e++) { l_run += pv[8 * kk + e]; pf[e] = (short)f2bf(pv[8 * kk + e]); }
+                if (k0 + 32 * kk < kend_w) {             // wave-uniform: later keys are masked for every query here
+#pragma unroll
+                    for (int n = 0; n < NDV; n++) {
+                        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lv[(32 * kk + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lv[(32 * kk + 16 + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                        const bf16x8_t vf = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        oacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = 1.0f / (STABLE ? fmaxf(l_run, 1e-9f) : l_run);
+    if (qi < p.S) {
+        T* og = (T*)p.o + ((long)b * p.S + qi) * p.ld_o + (long)h * p.d;
+#pragma unroll
+        for (int n = 0; n < NDV; n++) {
+            const int dv = 16 * n + 4 * fg;
+            if (dv < p.d) {                              // d % 4 == 0 on this path: whole 4-vectors only
+                const float o4[4] = {oacc[n][0] * inv, oacc[n][1] * inv, oacc[n][2] * inv, oacc[n][3] * inv};
+                VecIO<T, 4>::store(og + dv, o4);
+            }
+        }
+        if (p.lse && fg == 0) p.lse[((long)b * p.H + h) * p.S + qi] = STABLE ? l_run : (m_run + logf(l_run));
+    }
+}
+
+template <int DP, int KT>
+static int fwd2_launch(const AttnP& p, int mode, hipStream_t st) {
+    const size_t lds = (size_t)2 * KT * (DP + 8) * 2;
+    const dim3 grid((unsigned)cdiv(p.S, 64), (unsigned)(p.B * p.H));
+    if (mode == MM_ATTN_STABLEMAX) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)prefix_attn_fwd2_k<DP, KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((prefix_attn_fwd2_k<DP, KT, true>), grid, dim3(256), lds, st, p);
+    } else {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)prefix_attn_fwd2_k<DP, KT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((prefix_attn_fwd2_k<DP, KT, false>), grid, dim3(256), lds, st, p);
+    }
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+static int fwd2_dispatch(const AttnP& p, int mode, hipStream_t st) {
+    const int d = p.d;
+    if (d <= 32) return fwd2_launch<32, 64>(p, mode, st);
+    if (d <= 64) return fwd2_launch<64, 64>(p, mode, st);
+    if (d <= 128) return fwd2_launch<128, 64>(p, mode, st);
+    if (d <= 192) return fwd2_launch<192, 64>(p, mode, st);
+    if (d <= 256) return fwd2_launch<256, 32>(p, mode, st);
+    if (d <= 512) return fwd2_launch<512, 32>(p, mode, st);
+    MM_FAIL(MM_ERR_UNSUPPORTED, "prefix_attn: head_dim %d > 512", d);
+}
+
+// ------------------------------------------------------------------------------------------------
 // host dispatch (forward)
 // ------------------------------------------------------------------------------------------------
 template <typename T, int DP>
@@ -321,6 +509,8 @@ extern "C" int mm_prefix_attn_fwd(const void* q, const void* k, const void* v, v
     p.ld = ld_qkv; p.ld_o = H * d; p.scale = (float)(1.0 / sqrt((double)d));
     p.vec_ok = attn_vec_ok(q, k, v, ld_qkv, d, dtype);
     hipStream_t st = (hipStream_t)stream;
+    static const bool force_generic = getenv("MM_ATTN_GENERIC") != nullptr;     // A/B switch for debugging
+    if (!force_generic && dtype == MM_BF16 && rot == 0 && p.vec_ok && ((uintptr_t)o) % 8 == 0) return fwd2_dispatch(p, mode, st);
     return dtype == MM_BF16 ? fwd_dispatch<bf16>(p, mode, st) : fwd_dispatch<float>(p, mode, st);
 }
 

@@ -229,16 +229,17 @@ _rope_cache = {}
 def rope_tables(inv_freq: Tensor, seq_len: int):
     """cos/sin [S, rot/2] f32, computed as the reference does (transformer_decoder.py:18-22); the second half of
     the reference's table repeats the first (emb = cat(freqs, freqs)), so only rot/2 columns are kept."""
-    key = (inv_freq.data_ptr(), inv_freq.device, seq_len, inv_freq._version)
+    key = (inv_freq.data_ptr(), inv_freq.numel(), inv_freq.device, seq_len, inv_freq._version)
     hit = _rope_cache.get(key)
     if hit is None:
         t = torch.arange(seq_len, device=inv_freq.device)
         freqs = torch.einsum("i,j->ij", t, inv_freq.float())
-        hit = (freqs.cos().contiguous(), freqs.sin().contiguous())
+        # the entry keeps inv_freq alive: a freed buffer's address could otherwise come back with other contents
+        hit = (freqs.cos().contiguous(), freqs.sin().contiguous(), inv_freq)
         if len(_rope_cache) > 64:
             _rope_cache.clear()
         _rope_cache[key] = hit
-    return hit
+    return hit[0], hit[1]
 
 
 def _qkv_geom(q: Tensor, k: Tensor, v: Tensor, H: int):

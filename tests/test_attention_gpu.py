@@ -87,3 +87,37 @@ def test_decode_attn_matches_full_recompute(case, stablemax, dtype):
     for pos in range(P, S):
         o = ops.decode_attn(qkv_d[:, pos, 0], qkv_d[:, pos, 1], qkv_d[:, pos, 2], kc, vc, H, rot, pos, cos_t, sin_t, stablemax)
         assert rel_err(o.float().cpu(), ref[:, pos]) < TOL[dtype], pos
+
+
+@pytest.mark.parametrize("stablemax", [True, False])
+@pytest.mark.parametrize("case", CASES)
+def test_prefix_attn_prerotated_bf16_fast_path(case, stablemax):
+    """The product path: q,k rotated once by mm_rope_inplace, attention called with rot=0 (bf16 fast kernels),
+    gradients un-rotated by the inverse pre-pass."""
+    from multimodal_amd import ops
+    B, H, d, S, P = case
+    E = H * d
+    rot = int(d * 0.5)
+    rot -= rot % 2
+    dev = torch.device("cuda:0")
+    dtype = torch.bfloat16
+    qkv = _rand(B, S, 3, E, seed=11, scale=1.5).to(dtype)
+    q, k, v = (qkv[:, :, i].float().requires_grad_(True) for i in range(3))
+    ref = _oracle(q, k, v, H, rot, P, stablemax)
+    d_o = _rand(B, S, E, seed=12).to(dtype)
+    ref.backward(d_o.float())
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2).float() / rot))
+    cos_t, sin_t = ops.rope_tables(inv.to(dev), S)
+    qkv_d = qkv.to(dev)
+    qd, kd, vd = qkv_d[:, :, 0], qkv_d[:, :, 1], qkv_d[:, :, 2]
+    ops.rope_inplace(qd, H, rot, cos_t, sin_t)
+    ops.rope_inplace(kd, H, rot, cos_t, sin_t)
+    o, lse = ops.prefix_attn_fwd(qd, kd, vd, H, 0, P, cos_t, sin_t, stablemax, save_lse=True)
+    assert rel_err(o.float().cpu(), ref.detach()) < 2e-2
+    dqkv = ops.prefix_attn_bwd(qd, kd, vd, o, d_o.to(dev), lse, H, 0, P, cos_t, sin_t, stablemax)
+    ops.rope_inplace(dqkv[:, :, 0], H, rot, cos_t, sin_t, inverse=True)
+    ops.rope_inplace(dqkv[:, :, 1], H, rot, cos_t, sin_t, inverse=True)
+    torch.cuda.synchronize()
+    assert rel_err(dqkv[:, :, 2].float().cpu(), v.grad) < 3e-2
+    assert rel_err(dqkv[:, :, 0].float().cpu(), q.grad) < 3e-2
+    assert rel_err(dqkv[:, :, 1].float().cpu(), k.grad) < 3e-2
