@@ -164,6 +164,10 @@ int mm_layerscale_bwd(const void* dout, const void* z, const float* gamma, const
 /* argmax over the last dim of logits [rows][V] (row stride ld) -> int64 ids (train_autoregressive.py:102);
  * the first maximal index wins, as torch.argmax does. */
 int mm_argmax_rows(const void* logits, int64_t* out, int64_t rows, int64_t V, int64_t ld, int dtype, void* stream);
+/* Decoder MLP activation relu(h)^2 (models/transformer_decoder.py:161) over n elements, and its backward
+ * dh = da * 2*relu(h); dh may alias da. */
+int mm_relu2_fwd(const void* h, void* a, int64_t n, int dtype, void* stream);
+int mm_relu2_bwd(const void* h, const void* da, void* dh, int64_t n, int dtype, void* stream);
 
 /* ---- optimizer: OrthoGrad projection + AdamW, multi-tensor (next-row N3) ---------------------
  * replaces ortho_grad.py:60-99 + torch.optim.AdamW.step.  All tables are DEVICE arrays the caller builds once:

@@ -1,5 +1,6 @@
 // Small fused elementwise / reduction pieces around the GEMMs.
 #include "common.h"
+#include <algorithm>
 
 // ------------------------------------------------------------------------------------------------
 // LayerScale + DropPath backward (autograd of reference models/convnext.py:45-47):
@@ -28,13 +29,18 @@ __global__ void layerscale_bwd_k(const T* __restrict__ dout, const T* __restrict
     part[((long)blockIdx.y * 2 + 0) * C + c] = sg;
     part[((long)blockIdx.y * 2 + 1) * C + c] = sb;
 }
-__global__ void pair_reduce_k(const float* __restrict__ part, int nchunks, int C, float* __restrict__ o0, float* __restrict__ o1) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 2 * C) return;
+__global__ __launch_bounds__(256) void pair_reduce_k(const float* __restrict__ part, int nchunks, int C, float* __restrict__ o0,
+                                                     float* __restrict__ o1) {
+    __shared__ float red[4][64];                                   // 64 outputs x 4 chunk groups per block
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + cl;
     const int kind = idx / C, c = idx % C;
     float s = 0.f;
-    for (int k = 0; k < nchunks; k++) s += part[((long)k * 2 + kind) * C + c];
-    (kind ? o1 : o0)[c] = s;
+    if (idx < 2 * C)
+        for (int k = g; k < nchunks; k += 4) s += part[((long)k * 2 + kind) * C + c];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && idx < 2 * C) (kind ? o1 : o0)[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 static int ls_chunks(int64_t M) { int64_t c = cdiv(M, 32); if (c > 512) c = 512; if (c < 1) c = 1; return (int)c; }
 extern "C" size_t mm_layerscale_bwd_workspace(int64_t M, int64_t C) {
@@ -60,7 +66,7 @@ extern "C" int mm_layerscale_bwd(const void* dout, const void* z, const float* g
                            (int)rows_per_scale, (bf16*)dz, (float*)workspace, (int)M, (int)C, rpc);
     else MM_FAIL(MM_ERR_ARG, "layerscale_bwd: bad dtype %d", dtype);
     MM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(pair_reduce_k, dim3((unsigned)cdiv(2 * C, 256)), dim3(256), 0, st, (const float*)workspace, nchunks, (int)C, dgamma, dbias);
+    hipLaunchKernelGGL(pair_reduce_k, dim3((unsigned)cdiv(2 * C, 64)), dim3(256), 0, st, (const float*)workspace, nchunks, (int)C, dgamma, dbias);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
@@ -184,4 +190,54 @@ extern "C" int mm_orthograd_adamw(const mm_param_desc* descs, const int32_t* chu
                        do_ortho ? coef : nullptr, lr, beta1, beta2, adam_eps, weight_decay, bc1, bc2s);
     MM_LAUNCH_CHECK();
     return MM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// relu(h)^2 of the decoder MLP (reference models/transformer_decoder.py:161) and its backward
+//   fwd: a = max(h,0)^2          bwd: dh = da * 2*max(h,0)       (dh may alias da)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC, bool BWD>
+__global__ __launch_bounds__(256) void relu2_k(const T* __restrict__ h, const T* da, T* out, long nvec, long n) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+        float hv[VEC], ov[VEC];
+        VecIO<T, VEC>::load(h + i * VEC, hv);
+        if (BWD) VecIO<T, VEC>::load(da + i * VEC, ov);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+            const float r = fmaxf(hv[j], 0.f);
+            ov[j] = BWD ? ov[j] * (2.f * r) : r * r;
+        }
+        VecIO<T, VEC>::store(out + i * VEC, ov);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)                       // ragged tail (n % VEC elements)
+        for (long i = nvec * VEC; i < n; i++) {
+            const float r = fmaxf(to_f(h[i]), 0.f);
+            out[i] = from_f<T>(BWD ? to_f(da[i]) * (2.f * r) : r * r);
+        }
+}
+template <bool BWD>
+static int relu2_launch(const void* h, const void* da, void* out, int64_t n, int dtype, hipStream_t st) {
+    const bool al = (((uintptr_t)h | (uintptr_t)out | (uintptr_t)da) & 15) == 0;
+    if (dtype == MM_F32) {
+        const long nvec = al ? n / 4 : 0;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(std::max<long>(nvec, 1), 256), 256 * 16));
+        if (al) hipLaunchKernelGGL((relu2_k<float, 4, BWD>), dim3(grid), dim3(256), 0, st, (const float*)h, (const float*)da, (float*)out, nvec, (long)n);
+        else hipLaunchKernelGGL((relu2_k<float, 1, BWD>), dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 4096)), dim3(256), 0, st, (const float*)h, (const float*)da, (float*)out, (long)n, (long)n);
+    } else if (dtype == MM_BF16) {
+        const long nvec = al ? n / 8 : 0;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(std::max<long>(nvec, 1), 256), 256 * 16));
+        if (al) hipLaunchKernelGGL((relu2_k<bf16, 8, BWD>), dim3(grid), dim3(256), 0, st, (const bf16*)h, (const bf16*)da, (bf16*)out, nvec, (long)n);
+        else hipLaunchKernelGGL((relu2_k<bf16, 1, BWD>), dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 4096)), dim3(256), 0, st, (const bf16*)h, (const bf16*)da, (bf16*)out, (long)n, (long)n);
+    } else MM_FAIL(MM_ERR_ARG, "relu2: bad dtype %d", dtype);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+extern "C" int mm_relu2_fwd(const void* h, void* a, int64_t n, int dtype, void* stream) {
+    MM_CHECK(h && a && n > 0, "relu2_fwd: null pointer or empty");
+    return relu2_launch<false>(h, nullptr, a, n, dtype, (hipStream_t)stream);
+}
+extern "C" int mm_relu2_bwd(const void* h, const void* da, void* dh, int64_t n, int dtype, void* stream) {
+    MM_CHECK(h && da && dh && n > 0, "relu2_bwd: null pointer or empty");
+    return relu2_launch<true>(h, da, dh, n, dtype, (hipStream_t)stream);
 }

@@ -392,21 +392,59 @@ extern "C" int mm_gemm(const mm_gemm_args* a, void* stream) {
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void colsum_stage1_k(const T* __restrict__ x, float* __restrict__ part, int M, int N, long ld, int rows_per_chunk) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.x * 256 + threadIdx.x;                 // scalar form: any N / ld / alignment
     if (n >= N) return;
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
     float s = 0.f;
     for (int r = r0; r < r1; r++) s += to_f(x[(long)r * ld + n]);
     part[(long)blockIdx.y * N + n] = s;
 }
-__global__ void colsum_stage2_k(const float* __restrict__ part, float* __restrict__ out, int nchunks, int N) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int c = 0; c < nchunks; c++) s += part[(long)c * N + n];
-    out[n] = s;
+// vector form: a block covers 32*VEC columns x one row chunk; 8 row groups of 32 lanes, each lane 16 B per row
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void colsum_stage1v_k(const T* __restrict__ x, float* __restrict__ part, int M, int N, long ld,
+                                                        int rows_per_chunk) {
+    __shared__ float red[8][32 * VEC + 1];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int n0 = (blockIdx.x * 32 + cl) * VEC;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) s[j] = 0.f;
+    if (n0 < N) {
+#pragma unroll 4
+        for (int r = r0 + rg; r < r1; r += 8) {
+            float v[VEC];
+            VecIO<T, VEC>::load(x + (long)r * ld + n0, v);
+#pragma unroll
+            for (int j = 0; j < VEC; j++) s[j] += v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) red[rg][cl * VEC + j] = s[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 32 * VEC; c += 256) {
+        const int n = blockIdx.x * 32 * VEC + c;
+        if (n < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; g++) t += red[g][c];
+            part[(long)blockIdx.y * N + n] = t;
+        }
+    }
 }
-static int colsum_chunks(int64_t M) { int64_t c = cdiv(M, 64); if (c > 256) c = 256; if (c < 1) c = 1; return (int)c; }
+// out[n] = sum_c part[c][n]: a block covers 64 columns, 4 chunk groups
+__global__ __launch_bounds__(256) void colsum_stage2_k(const float* __restrict__ part, float* __restrict__ out, int nchunks, int N) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (n < N)
+        for (int c = g; c < nchunks; c += 4) s += part[(long)c * N + n];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && n < N) out[n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+static int colsum_chunks(int64_t M) { int64_t c = cdiv(M, 64); if (c > 160) c = 160; if (c < 1) c = 1; return (int)c; }
 extern "C" size_t mm_colsum_workspace(int64_t M, int64_t N) {
     if (M <= 0 || N <= 0) return 0;
     return (size_t)colsum_chunks(M) * (size_t)N * sizeof(float);
@@ -421,11 +459,17 @@ extern "C" int mm_colsum(const void* x, float* out, void* workspace, size_t work
     const int nchunks = (int)cdiv(M, rpc);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)cdiv(N, 256), (unsigned)nchunks);
-    if (dtype == MM_F32) hipLaunchKernelGGL(colsum_stage1_k<float>, grid, dim3(256), 0, st, (const float*)x, (float*)workspace, (int)M, (int)N, (long)ld, rpc);
-    else if (dtype == MM_BF16) hipLaunchKernelGGL(colsum_stage1_k<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (float*)workspace, (int)M, (int)N, (long)ld, rpc);
-    else MM_FAIL(MM_ERR_ARG, "colsum: bad dtype %d", dtype);
+    const int esz = dtype == MM_BF16 ? 2 : 4;
+    const bool vec_ok = (N % (16 / esz)) == 0 && ((ld * esz) % 16) == 0 && ((uintptr_t)x % 16) == 0;
+    if (dtype == MM_F32) {
+        if (vec_ok) hipLaunchKernelGGL((colsum_stage1v_k<float, 4>), dim3((unsigned)cdiv(N, 128), (unsigned)nchunks), dim3(256), 0, st, (const float*)x, (float*)workspace, (int)M, (int)N, (long)ld, rpc);
+        else hipLaunchKernelGGL(colsum_stage1_k<float>, grid, dim3(256), 0, st, (const float*)x, (float*)workspace, (int)M, (int)N, (long)ld, rpc);
+    } else if (dtype == MM_BF16) {
+        if (vec_ok) hipLaunchKernelGGL((colsum_stage1v_k<bf16, 8>), dim3((unsigned)cdiv(N, 256), (unsigned)nchunks), dim3(256), 0, st, (const bf16*)x, (float*)workspace, (int)M, (int)N, (long)ld, rpc);
+        else hipLaunchKernelGGL(colsum_stage1_k<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (float*)workspace, (int)M, (int)N, (long)ld, rpc);
+    } else MM_FAIL(MM_ERR_ARG, "colsum: bad dtype %d", dtype);
     MM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_stage2_k, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, (const float*)workspace, out, nchunks, (int)N);
+    hipLaunchKernelGGL(colsum_stage2_k, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, (const float*)workspace, out, nchunks, (int)N);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }

@@ -17,13 +17,28 @@ import torch.distributed as dist
 
 
 class GradBuckets:
-    def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 128 << 20, comm_dtype=None):
+    """p.grad become views into a few flat float buffers.  Every slot starts on a 256-byte boundary (GEMMs write
+    weight gradients straight into them).  `adjacent`: tuples of parameters whose slots must follow one another in
+    the given order, so that one GEMM can produce their stacked gradient (the fused q/k/v projection)."""
+
+    ALIGN = 64          # elements
+
+    def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 128 << 20, comm_dtype=None, adjacent=()):
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []           # dicts: flat, params, pending, work
-        cur, cur_n = [], 0
+        group_of = {}
+        for g in adjacent:
+            g = tuple(p for p in g if p.requires_grad)
+            for p in g:
+                group_of[p] = g
+        cur, cur_n, seen = [], 0, set()
         for p in reversed(self.params):
-            cur.append(p)
-            cur_n += p.numel()
+            if p in seen:
+                continue
+            for q in group_of.get(p, (p,)):
+                seen.add(q)
+                cur.append(q)
+                cur_n += -(-q.numel() // self.ALIGN) * self.ALIGN
             if cur_n * 4 >= bucket_bytes:
                 self._make(cur)
                 cur, cur_n = [], 0
@@ -32,17 +47,22 @@ class GradBuckets:
         self.comm_dtype = comm_dtype
 
     def _make(self, plist):
-        n = sum(p.numel() for p in plist)
+        n = sum(-(-p.numel() // self.ALIGN) * self.ALIGN for p in plist)
         flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
         off = 0
         for p in plist:
             p.grad = flat[off: off + p.numel()].view_as(p)
-            off += p.numel()
+            p._mm_slot = (flat, off)
+            off += -(-p.numel() // self.ALIGN) * self.ALIGN
         self.buckets.append(dict(flat=flat, params=list(plist), pending=len(plist), work=None))
 
     def zero(self):
+        """Zero every bucket and mark the parameters fresh: a node that produces a whole weight gradient in one GEMM
+        (functional._weight_grad) may then write its bucket slot directly instead of accumulating into it."""
         for b in self.buckets:
             b["flat"].zero_()
+            for p in b["params"]:
+                p._mm_fresh = True
 
 
 class DataParallel:
@@ -52,7 +72,8 @@ class DataParallel:
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.buckets = GradBuckets(list(module.parameters()), bucket_bytes)
+        adjacent = [g for m in module.modules() if hasattr(m, "stacked_grad_groups") for g in m.stacked_grad_groups()]
+        self.buckets = GradBuckets(list(module.parameters()), bucket_bytes, adjacent=adjacent)
         self.overlap = overlap and self.world > 1
         self._bucket_of = {}
         for b in self.buckets.buckets:
@@ -63,6 +84,7 @@ class DataParallel:
         if self.overlap:
             for p in self.buckets.params:
                 p.register_post_accumulate_grad_hook(self._hook)
+                p._mm_ready = self._hook          # called by nodes that write p.grad themselves
 
     def broadcast_parameters(self, src: int = 0):
         for t in list(self.module.parameters()) + list(self.module.buffers()):

@@ -4,6 +4,7 @@ inside the encoder.  Compute dtype: float32 (parity mode) or bfloat16 (throughpu
 always stay float32 masters and are cast per call when the compute dtype is bfloat16."""
 from __future__ import annotations
 
+import weakref
 from contextlib import contextmanager
 from typing import Optional
 
@@ -204,3 +205,148 @@ class PrefixAttention(torch.autograd.Function):
         ops.rope_inplace(dqkv[:, :, 0], H, rot, cos_t, sin_t, inverse=True)
         ops.rope_inplace(dqkv[:, :, 1], H, rot, cos_t, sin_t, inverse=True)
         return dqkv, None, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# Decoder layer as ONE autograd node.
+# --------------------------------------------------------------------------------------------------
+_operand_cache = {}
+
+
+def cached_operand(params, dtype) -> Tensor:
+    """Compute-dtype GEMM operand of one float32 master parameter, or of several stacked along dim 0 (the fused
+    q/k/v projection).  Rebuilt only when a parameter's version counter or storage moves; OrthoGradAdamW bumps the
+    counters of everything it updates, so the copy is made once per optimizer step instead of once per use."""
+    if len(params) == 1 and params[0].dtype == dtype:
+        return params[0].detach()
+    key = tuple(id(p) for p in params) + (dtype,)
+    stamp = tuple((p._version, p.data_ptr()) for p in params)
+    ent = _operand_cache.get(key)
+    if ent is not None and ent[0] == stamp and all(r() is p for r, p in zip(ent[2], params)):
+        return ent[1]
+    shape = (sum(p.shape[0] for p in params),) + tuple(params[0].shape[1:])
+    dev = params[0].device
+    buf = ent[1] if ent is not None and tuple(ent[1].shape) == shape and ent[1].device == dev else \
+        torch.empty(shape, dtype=dtype, device=dev)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            buf[off: off + p.shape[0]].copy_(p)
+            off += p.shape[0]
+    _operand_cache[key] = (stamp, buf, tuple(weakref.ref(p) for p in params))
+    return buf
+
+
+def _mm_f32(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """a @ b with a float32 result (bf16 operands accumulate and land in f32: weight gradients never see bf16)."""
+    if a.dtype == torch.float32:
+        return torch.mm(a, b, out=out) if out is not None else torch.mm(a, b)
+    if out is not None:
+        return torch.mm(a, b, out_dtype=torch.float32, out=out)
+    return torch.mm(a, b, out_dtype=torch.float32)
+
+
+def _weight_grad(p: Tensor, dy2: Tensor, x2: Tensor) -> Optional[Tensor]:
+    """dW = dy2^T @ x2 (float32).  When the data-parallel buckets have just zeroed p.grad (dp.GradBuckets marks the
+    parameter fresh) the GEMM writes the bucket slot directly and the bucket is told the gradient is ready; the node
+    then returns None for this parameter.  Otherwise the gradient goes back to autograd to be accumulated."""
+    g = p.grad
+    if g is not None and getattr(p, "_mm_fresh", False) and g.dtype == torch.float32 and g.is_contiguous() \
+            and g.shape == p.shape:
+        _mm_f32(dy2.t(), x2, out=g)
+        p._mm_fresh = False
+        ready = getattr(p, "_mm_ready", None)
+        if ready is not None:
+            ready(p)
+        return None
+    return _mm_f32(dy2.t(), x2)
+
+
+def _stacked_weight_grads(params, dy2: Tensor, x2: Tensor):
+    """Weight gradients of several projections that share an input (q/k/v): ONE GEMM into their adjacent bucket slots
+    when dp.GradBuckets laid them out that way and all are fresh; else one GEMM each."""
+    slots = [getattr(p, "_mm_slot", None) for p in params]
+    n = params[0].numel()
+    if all(s is not None for s in slots) and all(getattr(p, "_mm_fresh", False) and p.grad is not None for p in params) \
+            and all(s[0] is slots[0][0] and s[1] == slots[0][1] + i * n and p.numel() == n
+                    for i, (s, p) in enumerate(zip(slots, params))):
+        flat, off = slots[0]
+        out = flat[off: off + len(params) * n].view(len(params) * params[0].shape[0], params[0].shape[1])
+        _mm_f32(dy2.t(), x2, out=out)
+        for p in params:
+            p._mm_fresh = False
+            ready = getattr(p, "_mm_ready", None)
+            if ready is not None:
+                ready(p)
+        return [None] * len(params)
+    r = params[0].shape[0]
+    return [_weight_grad(p, dy2[:, i * r: (i + 1) * r], x2) for i, p in enumerate(params)]
+
+
+class DecoderLayer(torch.autograd.Function):
+    """DecoderPromptLayer.forward (reference models/transformer_decoder.py:115-166) as one node:
+         xa = LN1(x); qkv = xa Wqkv^T + b; RoPE(q,k) in place; o = K3(q,k,v); x1 = x + o Wo^T + bo
+         xf = LN2(x1); h = xf W1^T + b1; a = relu(h)^2; out = x1 + a W2^T + b2
+    Dense projections are plain library GEMMs (hipBLASLt through torch.mm/addmm) on cached bf16 operands; LayerNorm,
+    RoPE, attention, relu^2 and the bias-gradient column sums are libmmhip kernels; residual gradients are folded into
+    the LayerNorm backward kernels; weight gradients are produced in float32."""
+
+    @staticmethod
+    def forward(ctx, x, cos_t, sin_t, H, rot, prompt_len, stablemax, ln1w, ln1b, qw, qb, kw, kb, vw, vb, ow, ob,
+                ln2w, ln2b, w1, b1, w2, b2):
+        B, S, D = x.shape
+        M = B * S
+        dt = x.dtype
+        train = any(ctx.needs_input_grad)
+        x = x.contiguous()
+        xa, mean1, rstd1 = ops.layernorm_fwd(x, ln1w.detach(), ln1b.detach(), save_stats=train)
+        qkv = torch.addmm(cached_operand((qb, kb, vb), dt), xa.view(M, D), cached_operand((qw, kw, vw), dt).t())
+        qkv = qkv.view(B, S, 3, D)
+        ops.rope_inplace(qkv.view(B, S, 3 * D)[:, :, :2 * D], 2 * H, rot, cos_t, sin_t)      # q and k in one launch
+        o, lse = ops.prefix_attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], H, 0, prompt_len, cos_t, sin_t, stablemax,
+                                     save_lse=train)
+        x1 = torch.addmm(cached_operand((ob,), dt), o.view(M, D), cached_operand((ow,), dt).t()).add_(x.view(M, D))
+        xf, mean2, rstd2 = ops.layernorm_fwd(x1, ln2w.detach(), ln2b.detach(), save_stats=train)
+        h = torch.addmm(cached_operand((b1,), dt), xf, cached_operand((w1,), dt).t())
+        a = ops.relu2_fwd(h)
+        out = torch.addmm(cached_operand((b2,), dt), a, cached_operand((w2,), dt).t()).add_(x1)
+        if train:
+            ctx.save_for_backward(x, mean1, rstd1, xa, qkv, o, lse, x1, mean2, rstd2, xf, h, a, cos_t, sin_t,
+                                  ln1w, qw, kw, vw, ow, ln2w, w1, w2)
+            ctx.cfg = (H, rot, prompt_len, stablemax)
+        return out.view(B, S, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x, mean1, rstd1, xa, qkv, o, lse, x1, mean2, rstd2, xf, h, a, cos_t, sin_t,
+         ln1w, qw, kw, vw, ow, ln2w, w1, w2) = ctx.saved_tensors
+        H, rot, prompt_len, stablemax = ctx.cfg
+        B, S, D = x.shape
+        M = B * S
+        dt = x.dtype
+        F4 = h.shape[1]
+        dout = dout.contiguous().view(M, D)
+        # ---- MLP
+        db2 = ops.colsum(dout, M, D)
+        dw2 = _weight_grad(w2, dout, a)
+        dh = torch.mm(dout, cached_operand((w2,), dt))
+        ops.relu2_bwd_(h, dh)
+        db1 = ops.colsum(dh, M, F4)
+        dw1 = _weight_grad(w1, dh, xf)
+        dxf = torch.mm(dh, cached_operand((w1,), dt))
+        dx1, dln2w, dln2b = ops.layernorm_bwd(x1, dxf, dout, ln2w.detach(), mean2, rstd2)      # + residual gradient
+        # ---- attention
+        dbo = ops.colsum(dx1, M, D)
+        dwo = _weight_grad(ow, dx1, o.view(M, D))
+        d_o = torch.mm(dx1, cached_operand((ow,), dt)).view(B, S, D)
+        dqkv = ops.prefix_attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, d_o, lse, H, 0, prompt_len, cos_t, sin_t,
+                                   stablemax)                                               # saved q,k are rotated
+        ops.rope_inplace(dqkv.view(B, S, 3 * D)[:, :, :2 * D], 2 * H, rot, cos_t, sin_t, inverse=True)
+        dqkv2 = dqkv.view(M, 3 * D)
+        dbqkv = ops.colsum(dqkv2, M, 3 * D)
+        xa2 = xa.view(M, D)
+        dqw, dkw, dvw = _stacked_weight_grads((qw, kw, vw), dqkv2, xa2)
+        dxa = torch.mm(dqkv2, cached_operand((qw, kw, vw), dt))
+        dx, dln1w, dln1b = ops.layernorm_bwd(x, dxa.view(B, S, D), dx1.view(B, S, D), ln1w.detach(), mean1, rstd1)
+        return (dx, None, None, None, None, None, None, dln1w, dln1b, dqw, dbqkv[:D], dkw, dbqkv[D:2 * D], dvw,
+                dbqkv[2 * D:], dwo, dbo, dln2w, dln2b, dw1, db1, dw2, db2)

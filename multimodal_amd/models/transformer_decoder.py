@@ -1,7 +1,8 @@
 """Prompt decoder on the MI355X hot path: same classes / signatures / state_dict keys as reference
 models/transformer_decoder.py.  The attention core (RoPE, prefix-LM mask, softmax|stablemax, P.V) is ONE
-fused kernel (K3) and never materialises scores or the [B,H,S,S] mask; LayerNorms are libmmhip kernels;
-the dense projections run on the GPU BLAS through torch."""
+fused kernel (K3) and never materialises scores or the [B,H,S,S] mask; a whole layer is one autograd node
+(functional.DecoderLayer): LayerNorm, RoPE, attention, relu^2 and bias gradients are libmmhip kernels, the dense
+projections are plain library GEMMs (hipBLASLt through torch.mm) on cached bf16 operands."""
 import math
 
 import torch as th
@@ -73,15 +74,9 @@ class DecoderPromptLayer(nn.Module):
         self.mlp_dropout = nn.Dropout(0.0)
         self.intra_mlp_dropout = nn.Dropout(0.0)
 
-    def _qkv(self, xa, dt):
-        w = th.cat((self.q.weight, self.k.weight, self.v.weight), 0).to(dt)
-        b = th.cat((self.q.bias, self.k.bias, self.v.bias), 0).to(dt)
-        return F.linear(xa, w, b)
-
-    def _mlp(self, x, dt):
-        xf = FN.LayerNorm.apply(x, self.mlp_norm.weight, self.mlp_norm.bias)
-        xf = F.relu(_lin(xf, self.ffn_w1, dt)).square()
-        return x + _lin(xf, self.ffn_w2, dt)
+    def stacked_grad_groups(self):
+        """Parameters whose gradients one GEMM produces stacked (dp.GradBuckets keeps their slots adjacent)."""
+        return [(self.q.weight, self.k.weight, self.v.weight)]
 
     def forward(self, x, mask=None, prompt_len=None):
         """x: [B,S,D].  The reference passes the boolean prefix-LM mask [B,H,S,S]; here the mask is evaluated
@@ -92,13 +87,12 @@ class DecoderPromptLayer(nn.Module):
             if mask is None:
                 raise ValueError("DecoderPromptLayer needs prompt_len (or the reference's prefix-LM mask)")
             prompt_len = int(mask[0, 0, 0].sum().item())
-        x = x.to(dt)
-        xa = FN.LayerNorm.apply(x, self.attn_norm.weight, self.attn_norm.bias)
-        qkv = self._qkv(xa, dt).view(B, S, 3, D)
         cos_t, sin_t = self.rotary_emb.half_tables(S)
-        attn = FN.PrefixAttention.apply(qkv, cos_t, sin_t, self.nhead, self.rotary_ndims, prompt_len, self.use_stablemax)
-        x = _lin(attn, self.out, dt) + x
-        return self._mlp(x, dt)
+        return FN.DecoderLayer.apply(
+            x.to(dt), cos_t, sin_t, self.nhead, self.rotary_ndims, prompt_len, self.use_stablemax,
+            self.attn_norm.weight, self.attn_norm.bias, self.q.weight, self.q.bias, self.k.weight, self.k.bias,
+            self.v.weight, self.v.bias, self.out.weight, self.out.bias, self.mlp_norm.weight, self.mlp_norm.bias,
+            self.ffn_w1.weight, self.ffn_w1.bias, self.ffn_w2.weight, self.ffn_w2.bias)
 
 
 class SMILESDecoder(nn.Module):

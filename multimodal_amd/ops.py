@@ -329,6 +329,23 @@ def argmax_rows(logits: Tensor) -> Tensor:
     return out
 
 
+def relu2_fwd(h: Tensor) -> Tensor:
+    """relu(h)**2 (the decoder MLP activation)."""
+    _chk(h, "h")
+    a = torch.empty_like(h)
+    L.check(L.lib().mm_relu2_fwd(L.ptr(h), L.ptr(a), h.numel(), L.dtype_code(h), L.cur_stream()), "mm_relu2_fwd")
+    return a
+
+
+def relu2_bwd_(h: Tensor, da: Tensor) -> Tensor:
+    """da <- da * 2*relu(h), in place."""
+    _chk(h, "h"); _chk(da, "da", h.dtype)
+    if da.numel() != h.numel():
+        raise RuntimeError("relu2_bwd: shape mismatch")
+    L.check(L.lib().mm_relu2_bwd(L.ptr(h), L.ptr(da), L.ptr(da), h.numel(), L.dtype_code(h), L.cur_stream()), "mm_relu2_bwd")
+    return da
+
+
 def rope_inplace(x: Tensor, H: int, rot: int, cos_t: Tensor, sin_t: Tensor, inverse: bool = False) -> None:
     """x: [B,S,E] view (unit inner stride, batch stride S*row stride), rotated in place."""
     if rot == 0:

@@ -78,4 +78,6 @@ class OrthoGradAdamW(torch.optim.Optimizer):
                                                tab["n_tensors"], tab["n_chunks"], CHUNK, group["lr"], b1, b2, group["eps"],
                                                group["weight_decay"], self._step, group["ortho_eps"], int(group["rescale"]),
                                                int(group["ortho"]), L.ptr(ws), nbytes, L.cur_stream()), "mm_orthograd_adamw")
+            # the kernel writes through raw pointers: tell autograd (and functional.cached_operand) the values moved
+            torch.autograd.graph.increment_version(plist)
         return loss

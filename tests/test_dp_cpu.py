@@ -77,5 +77,15 @@ def test_grad_buckets_are_views():
         off = 0
         for p in b["params"]:
             assert p.grad.data_ptr() == b["flat"].data_ptr() + off * 4
-            off += p.numel()
+            assert p._mm_slot[0] is b["flat"] and p._mm_slot[1] == off
+            off += -(-p.numel() // GradBuckets.ALIGN) * GradBuckets.ALIGN      # slots are 256-byte aligned
         assert b["flat"].abs().sum() > 0
+
+
+def test_grad_buckets_keep_groups_adjacent():
+    from multimodal_amd.dp import GradBuckets
+    ps = [torch.nn.Parameter(torch.zeros(5, 3)) for _ in range(6)]
+    gb = GradBuckets(ps, bucket_bytes=1 << 30, adjacent=[(ps[1], ps[3], ps[4])])
+    assert sorted(id(p) for b in gb.buckets for p in b["params"]) == sorted(id(p) for p in ps)
+    step = -(-15 // GradBuckets.ALIGN) * GradBuckets.ALIGN
+    assert ps[3]._mm_slot[1] == ps[1]._mm_slot[1] + step and ps[4]._mm_slot[1] == ps[3]._mm_slot[1] + step
