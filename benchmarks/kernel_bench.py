@@ -68,6 +68,19 @@ def bench_attn(B, H, d, S, P, dtype, stablemax=True):
                 bwd_us=tb * 1e6, fwd_TFLOPs=fl / tf / 1e12, bwd_TFLOPs=2.5 * fl / tb / 1e12)
 
 
+def bench_ln(rows, C, dtype):
+    d = torch.device("cuda:0")
+    x = torch.randn(rows, C, device=d).to(dtype)
+    w = torch.ones(C, device=d); b = torch.zeros(C, device=d)
+    y, mean, rstd = ops.layernorm_fwd(x, w, b, save_stats=True)
+    dy = torch.randn_like(x); dres = torch.randn_like(x)
+    tf = timeit(lambda: ops.layernorm_fwd(x, w, b, save_stats=True))
+    tb = timeit(lambda: ops.layernorm_bwd(x, dy, dres, w, mean, rstd))
+    es = x.element_size()
+    return dict(kernel="layernorm", rows=rows, C=C, dtype=str(dtype), fwd_us=tf * 1e6, bwd_us=tb * 1e6,
+                fwd_GBps=rows * C * 2 * es / tf / 1e9, bwd_GBps=rows * C * 4 * es / tb / 1e9)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="k1,gemm")
@@ -90,6 +103,10 @@ if __name__ == "__main__":
                 res.append(bench_gemm(M, N, K, dt)); print(json.dumps(res[-1]), flush=True)
             res.append(bench_gemm(10080, 1600, 6400, dt, False, True)); print(json.dumps(res[-1]), flush=True)
             res.append(bench_gemm(6400, 1600, 10080, dt, True, True)); print(json.dumps(res[-1]), flush=True)
+    if "ln" in a.what.split(","):
+        for dt in (torch.bfloat16, torch.float32):
+            for (rows, C) in [(10080, 1600), (80640, 1600), (8000, 64), (992, 1600)]:
+                res.append(bench_ln(rows, C, dt)); print(json.dumps(res[-1]), flush=True)
     if "attn" in a.what:
         for (B, H, d, S, P, sm) in [(32, 16, 100, 315, 221, True), (32, 8, 128, 238, 159, False), (32, 4, 192, 315, 221, True), (32, 4, 512, 315, 221, True)]:
             res.append(bench_attn(B, H, d, S, P, torch.bfloat16, sm)); print(json.dumps(res[-1]), flush=True)

@@ -38,11 +38,16 @@ template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return __flo
 template <typename T, int VEC> struct VecIO;
 typedef __attribute__((ext_vector_type(4))) float mm_f4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned mm_u4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned mm_u2_t;
 template <> struct VecIO<float, 4> {
     static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
         float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    // raw form: keep the 16 loaded bytes packed until they are needed (several rows in flight per lane)
+    typedef mm_f4_t raw_t;
+    static __device__ __forceinline__ raw_t load_raw(const float* p) { return *reinterpret_cast<const mm_f4_t*>(p); }
+    static __device__ __forceinline__ void unpack(raw_t t, float (&v)[4]) { v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
     // non-temporal forms for once-touched streams (measured on K1: +4% fwd stores, +10% bwd loads)
     static __device__ __forceinline__ void load_nt(const float* p, float (&v)[4]) {
         mm_f4_t t = __builtin_nontemporal_load(reinterpret_cast<const mm_f4_t*>(p));
@@ -62,6 +67,12 @@ template <> struct VecIO<float, 1> {
     static __device__ __forceinline__ void store(float* p, const float (&v)[1]) { *p = v[0]; }
 };
 template <> struct VecIO<bf16, 8> {
+    typedef mm_u4_t raw_t;
+    static __device__ __forceinline__ raw_t load_raw(const bf16* p) { return *reinterpret_cast<const mm_u4_t*>(p); }
+    static __device__ __forceinline__ void unpack(raw_t t, float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { v[2 * i] = __uint_as_float(t[i] << 16); v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u); }
+    }
     static __device__ __forceinline__ void load(const bf16* p, float (&v)[8]) {
         uint4 t = *reinterpret_cast<const uint4*>(p);
         unsigned w[4] = {t.x, t.y, t.z, t.w};
@@ -78,6 +89,12 @@ template <> struct VecIO<bf16, 8> {
     static __device__ __forceinline__ void store_nt(bf16* p, const float (&v)[8]) { store(p, v); }
 };
 template <> struct VecIO<bf16, 4> {
+    typedef mm_u2_t raw_t;
+    static __device__ __forceinline__ raw_t load_raw(const bf16* p) { return *reinterpret_cast<const mm_u2_t*>(p); }
+    static __device__ __forceinline__ void unpack(raw_t t, float (&v)[4]) {
+        v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
+        v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+    }
     static __device__ __forceinline__ void load(const bf16* p, float (&v)[4]) {
         uint2 t = *reinterpret_cast<const uint2*>(p);
         v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);

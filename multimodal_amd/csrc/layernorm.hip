@@ -3,6 +3,7 @@
 // models/transformer_decoder.py:122,:160,:306, and the stem conv at models/convnext.py:68.
 // HBM-bound: one read of x, one write of y; one wave per row, row held in registers.
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // forward: wave per row, CH chunks of VEC per lane (C <= 64*VEC*CH)
@@ -154,15 +155,134 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* __restrict__ x, 
     }
 }
 
-__global__ void rows_reduce_k(const float* __restrict__ partial, int nrows, int width, float* __restrict__ out0,
-                              float* __restrict__ out1, int C) {
-    // out0[c] = sum_r partial[r][0][c], out1[c] = sum_r partial[r][1][c]; width = 2*C
-    __shared__ float red[4];
-    const int idx = blockIdx.x;
+// Wide rows (C > 512): one BLOCK walks rows, R at a time; a thread owns VEC*CH fixed channels, so the dw/db partials
+// need no cross-thread step.  The 3*R*CH 16-byte loads of a pass are issued together and stay packed in registers
+// (bf16 rows: 4 VGPRs per load) until used; each row is unpacked once for the sums and once for dx.
+template <typename T, int VEC, int CH, int R>
+__global__ __launch_bounds__(256) void layernorm_bwd_blk_k(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          const T* __restrict__ dres, const float* __restrict__ w,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          T* __restrict__ dx, float* __restrict__ partial, long rows_in,
+                                                          int Lin, int Lout, int C) {
+    typedef typename VecIO<T, VEC>::raw_t raw_t;
+    __shared__ float red[2][R][2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float pw[CH][VEC], pb[CH][VEC], wv[CH][VEC];
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int c = (k * 256 + tid) * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; i++) { pw[k][i] = 0.f; pb[k][i] = 0.f; wv[k][i] = (c + i < C) ? w[c + i] : 0.f; }
+    }
+    const float invC = 1.0f / (float)C;
+    int par = 0;
+    for (long row0 = (long)blockIdx.x * R; row0 < rows_in; row0 += (long)gridDim.x * R, par ^= 1) {
+        raw_t rx[R][CH], rg[R][CH], rr[R][CH];
+        float mu[R], rs[R];
+        bool live[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const long row = row0 + r;
+            const long g = row / Lin, l = row % Lin;
+            live[r] = row < rows_in && l < Lout;                               // block-uniform
+            const long row_o = g * Lout + l;
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const int c = (k * 256 + tid) * VEC;
+                rx[r][k] = raw_t{}; rg[r][k] = raw_t{}; rr[r][k] = raw_t{};
+                if (c < C) {
+                    if (live[r]) { rx[r][k] = VecIO<T, VEC>::load_raw(x + row * C + c); rg[r][k] = VecIO<T, VEC>::load_raw(dy + row_o * C + c); }
+                    if (dres && row < rows_in) rr[r][k] = VecIO<T, VEC>::load_raw(dres + row * C + c);
+                }
+            }
+            mu[r] = live[r] ? mean[row_o] : 0.f;
+            rs[r] = live[r] ? rstd[row_o] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                float xv[VEC], gy[VEC];
+                VecIO<T, VEC>::unpack(rx[r][k], xv);
+                VecIO<T, VEC>::unpack(rg[r][k], gy);
+#pragma unroll
+                for (int i = 0; i < VEC; i++) {
+                    const float h = (xv[i] - mu[r]) * rs[r];                  // dead row / channel: rs = 0 or gy = w = 0
+                    const float g = gy[i] * wv[k][i];
+                    s1 += g; s2 = fmaf(g, h, s2);
+                    pw[k][i] = fmaf(gy[i], h, pw[k][i]);
+                    pb[k][i] += gy[i];
+                }
+            }
+            s1 = wave_sum(s1); s2 = wave_sum(s2);
+            if (lane == 0) { red[par][r][0][wave] = s1; red[par][r][1][wave] = s2; }
+        }
+        __syncthreads();      // the other parity's slots are rewritten only after every thread passed this barrier
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const long row = row0 + r;
+            if (row < rows_in) {
+                const float m1 = ((red[par][r][0][0] + red[par][r][0][1]) + (red[par][r][0][2] + red[par][r][0][3])) * invC;
+                const float m2 = ((red[par][r][1][0] + red[par][r][1][1]) + (red[par][r][1][2] + red[par][r][1][3])) * invC;
+#pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    const int c = (k * 256 + tid) * VEC;
+                    if (c < C) {
+                        float xv[VEC], gy[VEC], o[VEC];
+                        VecIO<T, VEC>::unpack(rx[r][k], xv);
+                        VecIO<T, VEC>::unpack(rg[r][k], gy);
+                        VecIO<T, VEC>::unpack(rr[r][k], o);
+#pragma unroll
+                        for (int i = 0; i < VEC; i++) {
+                            const float h = (xv[i] - mu[r]) * rs[r];
+                            o[i] += rs[r] * (gy[i] * wv[k][i] - m1 - h * m2);
+                        }
+                        VecIO<T, VEC>::store(dx + row * C + c, o);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int c = (k * 256 + tid) * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; i++)
+            if (c + i < C) {
+                partial[((long)blockIdx.x * 2 + 0) * C + c + i] = pw[k][i];
+                partial[((long)blockIdx.x * 2 + 1) * C + c + i] = pb[k][i];
+            }
+    }
+}
+
+// out0[c] = sum_r partial[r][c], out1[c] = sum_r partial[r][C + c]  (width = 2*C); a block covers 16 columns with
+// 16 row groups (64-byte coalesced reads, 8 loads in flight per thread), fixed summation order.
+__global__ __launch_bounds__(256) void rows_reduce_k(const float* __restrict__ partial, int nrows, int width,
+                                                     float* __restrict__ out0, float* __restrict__ out1, int C) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + cl;
     float s = 0.f;
-    for (int r = threadIdx.x; r < nrows; r += 256) s += partial[(long)r * width + idx];
-    s = block_sum<4>(s, red);
-    if (threadIdx.x == 0) { if (idx < C) out0[idx] = s; else out1[idx - C] = s; }
+    if (idx < width) {
+        int r = g;
+        for (; r + 7 * 16 < nrows; r += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = partial[(long)(r + u * 16) * width + idx];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; r < nrows; r += 16) s += partial[(long)r * width + idx];
+    }
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && idx < width) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t += red[k][cl];
+        if (idx < C) out0[idx] = t; else out1[idx - C] = t;
+    }
 }
 
 template <typename T>
@@ -196,15 +316,19 @@ extern "C" int mm_layernorm_fwd(const void* x, const float* w, const float* b, v
     MM_FAIL(MM_ERR_ARG, "layernorm_fwd: bad dtype %d", dtype);
 }
 
-static int64_t ln_bwd_blocks(int64_t rows) {
-    int64_t nb = cdiv(rows, 4 * 4);        // ~4 rows per wave at least
-    if (nb > 1024) nb = 1024;
+#define LN_BWD_R 4
+static bool ln_bwd_wide(int64_t C) { return C > 512 && C % 4 == 0; }
+static int64_t ln_bwd_blocks(int64_t rows, int64_t C) {
+    int64_t nb = ln_bwd_wide(C) ? cdiv(rows, 4) : cdiv(rows, 4 * 4);        // wide: 4 rows per block pass
+    static const int64_t wide_cap = getenv("MM_LN_CAP") ? atoi(getenv("MM_LN_CAP")) : 512;
+    const int64_t cap = ln_bwd_wide(C) ? wide_cap : 1024;
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return nb;
 }
 extern "C" size_t mm_layernorm_bwd_workspace(int64_t rows, int64_t C) {
     if (rows <= 0 || C <= 0) return 0;
-    return (size_t)ln_bwd_blocks(rows) * 2 * (size_t)C * sizeof(float);
+    return (size_t)ln_bwd_blocks(rows, C) * 2 * (size_t)C * sizeof(float);
 }
 
 template <typename T>
@@ -214,15 +338,29 @@ static int ln_bwd_launch(const void* x, const void* dy, const void* dres, const 
     const long rows_in = G * Lin;
 #define L_(VEC_, CH_) hipLaunchKernelGGL((layernorm_bwd_k<T, VEC_, CH_>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, \
                                          (const T*)dy, (const T*)dres, w, mean, rstd, (T*)dx, partial, rows_in, (int)Lin, (int)Lout, (int)C)
-    if (C % 4 == 0) {
-        if (C <= 256) L_(4, 1); else if (C <= 512) L_(4, 2); else if (C <= 1024) L_(4, 4);
-        else if (C <= 2048) L_(4, 8);
-        else MM_FAIL(MM_ERR_UNSUPPORTED, "layernorm_bwd: C=%lld > 2048", (long long)C);
+#define W_(VEC_, CH_) hipLaunchKernelGGL((layernorm_bwd_blk_k<T, VEC_, CH_, LN_BWD_R>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, \
+                                         (const T*)dy, (const T*)dres, w, mean, rstd, (T*)dx, partial, rows_in, (int)Lin, (int)Lout, (int)C)
+    if (ln_bwd_wide(C)) {
+        bool done = false;
+        if constexpr (sizeof(T) == 2) {
+            if (C % 8 == 0) {
+                if (C <= 2048) W_(8, 1); else if (C <= 4096) W_(8, 2);
+                else MM_FAIL(MM_ERR_UNSUPPORTED, "layernorm_bwd: C=%lld > 4096", (long long)C);
+                done = true;
+            }
+        }
+        if (!done) {
+            if (C <= 1024) W_(4, 1); else if (C <= 2048) W_(4, 2); else if (C <= 4096) W_(4, 4);
+            else MM_FAIL(MM_ERR_UNSUPPORTED, "layernorm_bwd: C=%lld > 4096", (long long)C);
+        }
+    } else if (C % 4 == 0) {
+        if (C <= 256) L_(4, 1); else L_(4, 2);
     } else {
         if (C <= 64) L_(1, 1); else if (C <= 256) L_(1, 4); else if (C <= 1024) L_(1, 16);
         else MM_FAIL(MM_ERR_UNSUPPORTED, "layernorm_bwd: C=%lld (not a multiple of 4) > 1024", (long long)C);
     }
 #undef L_
+#undef W_
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
@@ -235,14 +373,14 @@ extern "C" int mm_layernorm_bwd(const void* x, const void* dy, const void* dres,
     MM_CHECK(G > 0 && Lin > 0 && Lout > 0 && Lout <= Lin && C > 0, "layernorm_bwd: bad shape");
     const int64_t rows = G * Lin;
     MM_CHECK(workspace_bytes >= mm_layernorm_bwd_workspace(rows, C), "layernorm_bwd: workspace too small");
-    const int64_t nb = ln_bwd_blocks(rows);
+    const int64_t nb = ln_bwd_blocks(rows, C);
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (dtype == MM_F32) rc = ln_bwd_launch<float>(x, dy, dres, w, mean, rstd, dx, (float*)workspace, nb, G, Lin, Lout, C, st);
     else if (dtype == MM_BF16) rc = ln_bwd_launch<bf16>(x, dy, dres, w, mean, rstd, dx, (float*)workspace, nb, G, Lin, Lout, C, st);
     else MM_FAIL(MM_ERR_ARG, "layernorm_bwd: bad dtype %d", dtype);
     if (rc != MM_OK) return rc;
-    hipLaunchKernelGGL(rows_reduce_k, dim3((unsigned)(2 * C)), dim3(256), 0, st, (const float*)workspace, (int)nb, (int)(2 * C), dw,
+    hipLaunchKernelGGL(rows_reduce_k, dim3((unsigned)cdiv(2 * C, 16)), dim3(256), 0, st, (const float*)workspace, (int)nb, (int)(2 * C), dw,
                        db, (int)C);
     MM_LAUNCH_CHECK();
     return MM_OK;

@@ -125,7 +125,8 @@ def test_stem_ln(B, Lin, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("G,Lin,Lout,C", [(1, 37, 37, 64), (3, 125, 124, 128), (2, 62, 62, 256), (2, 31, 30, 1600),
-                                          (1, 9, 9, 200), (2, 5, 5, 2048), (1, 6, 6, 50), (1, 3, 3, 768)])
+                                          (1, 9, 9, 200), (2, 5, 5, 2048), (1, 6, 6, 50), (1, 3, 3, 768), (2, 7, 7, 4096),
+                                          (1, 5, 4, 1028), (1, 1, 1, 516)])
 def test_layernorm(G, Lin, Lout, C, dtype):
     from multimodal_amd import ops
     x = _rand(G, Lin, C, seed=1).to(dtype).float().requires_grad_(True)
