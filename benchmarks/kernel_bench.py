@@ -46,8 +46,15 @@ def bench_gemm(M, N, K, dtype, akm=False, bkm=False):
     b = (torch.rand((K, N) if bkm else (N, K), device=d) * 2 - 1).to(dtype)
     t = timeit(lambda: ops.gemm(a, b, M, N, K, a_kmajor=akm, b_kmajor=bkm))
     tt = timeit(lambda: torch.matmul(a.t() if akm else a, b if bkm else b.t()))
-    return dict(kernel="gemm", M=M, N=N, K=K, dtype=str(dtype), layout=f"{int(akm)}{int(bkm)}", us=t * 1e6,
-                TFLOPs=2 * M * N * K / t / 1e12, torch_TFLOPs=2 * M * N * K / tt / 1e12)
+    r = dict(kernel="gemm", M=M, N=N, K=K, dtype=str(dtype), layout=f"{int(akm)}{int(bkm)}", us=t * 1e6,
+             TFLOPs=2 * M * N * K / t / 1e12, torch_TFLOPs=2 * M * N * K / tt / 1e12)
+    if not akm and not bkm:            # fused bias + residual epilogue vs library addmm + add
+        bias = torch.randn(N, device=d); res = torch.randn(M, N, device=d).to(dtype)
+        te = timeit(lambda: ops.gemm(a, b, M, N, K, bias=bias, res=res))
+        bb = bias.to(dtype)
+        tte = timeit(lambda: torch.addmm(bb, a, b.t()).add_(res))
+        r.update(us_bias_res=te * 1e6, torch_us_bias_res=tte * 1e6)
+    return r
 
 
 def bench_attn(B, H, d, S, P, dtype, stablemax=True):
@@ -84,6 +91,7 @@ def bench_ln(rows, C, dtype):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="k1,gemm")
+    ap.add_argument("--shapes", default="", help="gemm shapes M,N,K;M,N,K... (bf16 NT) for --what gemmx")
     a = ap.parse_args()
     res = []
     if "quick1" in a.what:
@@ -97,7 +105,7 @@ if __name__ == "__main__":
                 res.append(bench_k1(B, C, Ln, dt)); print(json.dumps(res[-1]), flush=True)
             for (B, C, Ln) in [(8192, 64, 250), (8192, 256, 62), (2048, 1600, 31), (32, 64, 250)]:
                 res.append(bench_k1(B, C, Ln, dt, bwd=True)); print(json.dumps(res[-1]), flush=True)
-    if "gemm" in a.what:
+    if "gemm" in a.what.split(","):
         for dt in (torch.bfloat16, torch.float32):
             for (M, N, K) in [(10080, 6400, 1600), (10080, 1600, 6400), (10080, 1600, 1600), (992, 6400, 1600), (992, 1600, 6400), (8000, 256, 64), (4096, 4096, 4096)]:
                 res.append(bench_gemm(M, N, K, dt)); print(json.dumps(res[-1]), flush=True)
@@ -107,6 +115,10 @@ if __name__ == "__main__":
         for dt in (torch.bfloat16, torch.float32):
             for (rows, C) in [(10080, 1600), (80640, 1600), (8000, 64), (992, 1600)]:
                 res.append(bench_ln(rows, C, dt)); print(json.dumps(res[-1]), flush=True)
+    if "gemmx" in a.what:
+        for sh in a.shapes.split(";"):
+            M, N, K = (int(v) for v in sh.split(","))
+            res.append(bench_gemm(M, N, K, torch.bfloat16)); print(json.dumps(res[-1]), flush=True)
     if "attn" in a.what:
         for (B, H, d, S, P, sm) in [(32, 16, 100, 315, 221, True), (32, 8, 128, 238, 159, False), (32, 4, 192, 315, 221, True), (32, 4, 512, 315, 221, True)]:
             res.append(bench_attn(B, H, d, S, P, torch.bfloat16, sm)); print(json.dumps(res[-1]), flush=True)

@@ -168,6 +168,9 @@ int mm_argmax_rows(const void* logits, int64_t* out, int64_t rows, int64_t V, in
  * dh = da * 2*relu(h); dh may alias da. */
 int mm_relu2_fwd(const void* h, void* a, int64_t n, int dtype, void* stream);
 int mm_relu2_bwd(const void* h, const void* da, void* dh, int64_t n, int dtype, void* stream);
+/* out[c][r] = (out_dtype) in[r][c]: transposed compute-dtype copy of an f32 [R][C] weight (row stride ldo >= R), the
+ * operand that makes dX = dY . W (autograd of nn.Linear, models/transformer_decoder.py:159-163) K-contiguous. */
+int mm_cast_transpose(const float* in, void* out, int64_t R, int64_t C, int64_t ldo, int out_dtype, void* stream);
 
 /* ---- optimizer: OrthoGrad projection + AdamW, multi-tensor (next-row N3) ---------------------
  * replaces ortho_grad.py:60-99 + torch.optim.AdamW.step.  All tables are DEVICE arrays the caller builds once:

@@ -241,3 +241,35 @@ extern "C" int mm_relu2_bwd(const void* h, const void* da, void* dh, int64_t n, 
     MM_CHECK(h && da && dh && n > 0, "relu2_bwd: null pointer or empty");
     return relu2_launch<true>(h, da, dh, n, dtype, (hipStream_t)stream);
 }
+
+// ------------------------------------------------------------------------------------------------
+// out[c][r] (bf16 or f32, row stride ldo) = in[r][c] (f32 master weight [R][C]): the transposed compute-dtype
+// operand copy that turns dX = dY . W into a K-contiguous product.  64 x 64 tiles through LDS.
+// ------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void cast_transpose_k(const float* __restrict__ in, TO* __restrict__ out, int R, int C, long ldo) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        tile[ty + 4 * i][tx] = (r < R && c < C) ? in[(long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (c < C && r < R) out[(long)c * ldo + r] = from_f<TO>(tile[tx][ty + 4 * i]);
+    }
+}
+extern "C" int mm_cast_transpose(const float* in, void* out, int64_t R, int64_t C, int64_t ldo, int out_dtype, void* stream) {
+    MM_CHECK(in && out && R > 0 && C > 0 && ldo >= R, "cast_transpose: bad arguments");
+    const dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 64));
+    hipStream_t st = (hipStream_t)stream;
+    if (out_dtype == MM_BF16) hipLaunchKernelGGL(cast_transpose_k<bf16>, grid, dim3(256), 0, st, in, (bf16*)out, (int)R, (int)C, (long)ldo);
+    else if (out_dtype == MM_F32) hipLaunchKernelGGL(cast_transpose_k<float>, grid, dim3(256), 0, st, in, (float*)out, (int)R, (int)C, (long)ldo);
+    else MM_FAIL(MM_ERR_ARG, "cast_transpose: bad dtype %d", out_dtype);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}

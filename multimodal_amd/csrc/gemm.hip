@@ -11,19 +11,8 @@
 // The MFMA is issued as (B-fragment, A-fragment): D's register index then runs along N, so every lane
 // owns 4 consecutive output columns and the epilogue moves 8/16 bytes per lane.
 #include "common.h"
-
-struct GemmP {
-    const void* A; const void* B; void* out;
-    int M, N, K;
-    long lda, ldb, ldo;
-    const float* bias; void* pre; const void* mul; int act;
-    const float* gamma; const float* rowscale; int rows_per_scale;
-    const void* res;
-    int a_vec, b_vec, o_vec;       // 16-byte path legal for A / B loads, out-family accesses
-    int k_per_split;               // K range per blockIdx.z
-    float* partial;                // split-K slabs [z][M][N] (f32) or NULL
-    int tiles_m, tiles_n;
-};
+#include "gemm_epi.h"
+#include <stdlib.h>
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -50,17 +39,6 @@ __device__ __forceinline__ void load_vec(const T* __restrict__ base, bool vec_ok
         for (int j = 0; j < E; j++)
             out[j] = (slow < slow_lim && fast + j < fast_lim) ? base[slow * ld + fast + j] : T(0.0f);
     }
-}
-
-__device__ __forceinline__ float act_fwd(int act, float v) {
-    if (act == 1) return gelu_erf(v);
-    if (act == 2) { const float r = fmaxf(v, 0.f); return r * r; }
-    return v;
-}
-__device__ __forceinline__ float act_bwd(int act, float pre) {
-    if (act == 1) return gelu_erf_grad(pre);
-    if (act == 2) return 2.f * fmaxf(pre, 0.f);
-    return 1.f;
 }
 
 template <typename T, typename TO, int BM, int BN, bool AKM, bool BKM, bool FAST>
@@ -225,7 +203,6 @@ __global__ __launch_bounds__(256, GEMM_MIN_WAVES) void gemm_k(const GemmP p) {
     }
 
     // ---- epilogue: lane owns columns n..n+3 of row m for each (i,j) tile
-    TO* __restrict__ out = (TO*)p.out;
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const long m = m0 + wm * WM + i * 16 + fr;
@@ -236,52 +213,7 @@ __global__ __launch_bounds__(256, GEMM_MIN_WAVES) void gemm_k(const GemmP p) {
             const long n = n0 + wn * WN + j * 16 + fg * 4;
             if (n >= p.N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.partial) {
-                float* dst = p.partial + ((long)blockIdx.z * p.M + m) * p.N + n;
-#pragma unroll
-                for (int e = 0; e < 4; e++) if (n + e < p.N) dst[e] = v[e];
-                continue;
-            }
-            const bool full = FAST || (p.o_vec && n + 4 <= p.N);
-            const long off = m * p.ldo + n;
-            if (p.bias) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) if (n + e < p.N) v[e] += p.bias[n + e];
-            }
-            if (p.pre) {
-                TO* pre = (TO*)p.pre;
-                if (full) VecIO<TO, 4>::store(pre + off, v);
-                else { for (int e = 0; e < 4; e++) if (n + e < p.N) pre[off + e] = from_f<TO>(v[e]); }
-            }
-            if (p.mul) {
-                const TO* mul = (const TO*)p.mul;
-                float h[4] = {0.f, 0.f, 0.f, 0.f};
-                if (full) VecIO<TO, 4>::load(mul + off, h);
-                else { for (int e = 0; e < 4; e++) if (n + e < p.N) h[e] = to_f(mul[off + e]); }
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] *= act_bwd(p.act, h[e]);
-            } else if (p.act) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = act_fwd(p.act, v[e]);
-            }
-            if (p.gamma) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) if (n + e < p.N) v[e] *= p.gamma[n + e];
-            }
-            if (p.rowscale) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] *= rscale;
-            }
-            if (p.res) {
-                const TO* res = (const TO*)p.res;
-                float h[4] = {0.f, 0.f, 0.f, 0.f};
-                if (full) VecIO<TO, 4>::load(res + off, h);
-                else { for (int e = 0; e < 4; e++) if (n + e < p.N) h[e] = to_f(res[off + e]); }
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] += h[e];
-            }
-            if (full) VecIO<TO, 4>::store(out + off, v);
-            else { for (int e = 0; e < 4; e++) if (n + e < p.N) out[off + e] = from_f<TO>(v[e]); }
+            gemm_epilogue4<TO, FAST>(p, v, m, n, rscale, blockIdx.z);
         }
     }
 }
@@ -330,6 +262,9 @@ static void launch_tile(GemmP& p, int akm, int bkm, int splits, hipStream_t st) 
     }
 }
 
+bool gemm_big_applicable(const GemmP& p, int dtype, int a_kmajor, int b_kmajor, int splits);
+int gemm_big_launch(GemmP& p, int out_dtype, hipStream_t st);
+
 extern "C" int mm_gemm(const mm_gemm_args* a, void* stream) {
     MM_CHECK(a && a->A && a->B && a->out, "gemm: null pointer");
     MM_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gemm: empty shape M=%lld N=%lld K=%lld", (long long)a->M, (long long)a->N, (long long)a->K);
@@ -367,6 +302,8 @@ extern "C" int mm_gemm(const mm_gemm_args* a, void* stream) {
         p.k_per_split = p.K;
     }
     hipStream_t st = (hipStream_t)stream;
+    static const bool no256 = getenv("MM_GEMM_NO256") != nullptr;          // A/B switch for benchmarks
+    if (!no256 && gemm_big_applicable(p, a->dtype, a->a_kmajor, a->b_kmajor, splits)) return gemm_big_launch(p, a->out_dtype, st);
     if (a->dtype == MM_BF16) {
         if (a->out_dtype == MM_BF16) launch_tile<bf16, bf16>(p, a->a_kmajor, a->b_kmajor, splits, st);
         else launch_tile<bf16, float>(p, a->a_kmajor, a->b_kmajor, splits, st);

@@ -1,0 +1,289 @@
+// Large-tile bf16 GEMM for the decoder projections:  out[M][N] = epi( A[M][K] . B[N][K]^T ), both operands K-contiguous.
+// One 512-thread workgroup (8 waves as 2(M) x 4(N)) owns a BM x BN output tile, BM = 32*TM, BN = 64*TN (a wave
+// accumulates TM x TN MFMA 16x16x32 tiles); the K loop moves 64 columns a step.
+//   * operands go global -> LDS directly (global_load_lds, 16 bytes per lane, no VGPR staging), two LDS stages:
+//     the loads of tile k+1 are in flight while tile k is multiplied; one barrier per K tile;
+//   * LDS image: rows of 128 bytes, the 16-byte chunk c of row r sits in slot c ^ ((r>>1)&7).  A ds_read_b128
+//     wave-instruction is served in 16-lane groups (16 rows, one chunk): rows r, r^1 fall in the two halves of a
+//     256-byte bank row and the 8 row pairs in 8 different slots -> conflict-free.  The DMA writes LDS linearly
+//     (wave base + lane*16), so the permutation is applied to each lane's SOURCE address;
+//   * rows past M / N are clamped to the last row on load (their products are never stored); K must be a
+//     multiple of 64 (the caller falls back to gemm_k otherwise);
+//   * epilogue through LDS: accumulators are transposed 32 rows a pass through a per-wave window and leave in a
+//     rolled loop, 8 consecutive columns per lane (16-byte global accesses, compact code);
+//   * the tile shape is chosen per problem from a small set by wave quantisation (tiles vs 256 CUs).
+// Tile order: XCD-aware bijective remap, N-fastest, so the 8 XCD-private L2s each keep a band of A rows.
+#include "common.h"
+#include "gemm_epi.h"
+#include <stdlib.h>
+
+namespace {
+constexpr int BK = 64;
+constexpr int kNumCU = 256;
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+// 8 consecutive output-type elements kept packed in registers until used
+template <typename TO> struct Raw8;
+template <> struct Raw8<bf16> {
+    mm_u4_t r;
+    __device__ __forceinline__ void load(const bf16* q) { r = *reinterpret_cast<const mm_u4_t*>(q); }
+    __device__ __forceinline__ void unpack(float (&v)[8]) const { VecIO<bf16, 8>::unpack(r, v); }
+};
+template <> struct Raw8<float> {
+    mm_f4_t a, b;
+    __device__ __forceinline__ void load(const float* q) { a = *reinterpret_cast<const mm_f4_t*>(q); b = *reinterpret_cast<const mm_f4_t*>(q + 4); }
+    __device__ __forceinline__ void unpack(float (&v)[8]) const {
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v[e] = a[e]; v[4 + e] = b[e]; }
+    }
+};
+
+template <int TM, int TN> struct BigTile {
+    static constexpr int BM = 32 * TM, BN = 64 * TN;
+    static constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    static constexpr int EPI_ROW = TN * 64 + 16;                       // padded f32 row of a wave's window (bytes)
+    static constexpr int EPI_WAVE = 16 * EPI_ROW;                      // 16 rows a pass; 8 windows fit in ONE stage
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int PIECES = (BM + BN) / 8;                       // 1 KiB DMA pieces (8 rows) per stage
+    static constexpr int PPW = (PIECES + 7) / 8;                       // pieces per wave (the last may be absent)
+    static_assert(8 * EPI_WAVE <= STAGE_BYTES, "epilogue windows must fit in stage 1");
+};
+
+template <typename TO, int TM, int TN>
+__global__ __launch_bounds__(512, 1) void gemm_big_k(const GemmP p) {
+    typedef BigTile<TM, TN> G;
+    constexpr int BM = G::BM, BN = G::BN;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int nk = p.K / BK;
+    const int nwg = p.tiles_m * p.tiles_n;
+
+    // ---- fragment read offsets (bytes inside a stage)
+    const int fr = lane & 15, fg = lane >> 4;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+        const int slot = ((ks * 4 + fg) ^ (fr >> 1)) << 4;
+        offA[ks] = (wr * (BM / 2) + fr) * 128 + slot;
+        offB[ks] = (BM + wc * (BN / 4) + fr) * 128 + slot;
+    }
+
+    // ---- staging: piece q = wave + 8*i covers rows 8q .. 8q+7 of the stacked [A rows ; B rows] image
+    const bf16* src[G::PPW];
+    auto tile_origin = [&](int id, long& m0, long& n0) {              // XCD-aware bijective remap, N fastest
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        m0 = (long)(wg / p.tiles_n) * BM; n0 = (long)(wg % p.tiles_n) * BN;
+    };
+    auto set_sources = [&](long m0, long n0) {
+#pragma unroll
+        for (int i = 0; i < G::PPW; i++) {
+            const int q = wave + 8 * i;
+            const int row = q * 8 + (lane >> 3);                       // stacked row; the swizzle uses the operand-local row
+            const bool isA = row < BM;
+            const int lrow = isA ? row : row - BM;
+            const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);
+            long gr = (isA ? m0 : n0) + lrow;
+            const long lim = (isA ? p.M : p.N) - 1;
+            if (gr > lim) gr = lim;
+            src[i] = (isA ? (const bf16*)p.A + gr * p.lda : (const bf16*)p.B + gr * p.ldb) + chunk * 8;
+        }
+    };
+    auto stage = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * G::STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < G::PPW; i++) {
+            const int q = wave + 8 * i;
+            if (q < G::PIECES)                                         // wave-uniform
+                __builtin_amdgcn_global_load_lds((glb_vp)(src[i] + (long)kt * BK), (lds_vp)(base + q * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- one output tile per workgroup (a persistent variant with next-tile prefetch measured no faster and cost
+    // ~50 VGPRs: the epilogue's stores are counted by the same vmcnt the next tile's first wait needs)
+    long m0, n0;
+    tile_origin(blockIdx.x, m0, n0);
+    set_sources(m0, n0);
+    stage(0, 0);
+    {
+        f32x4_t acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < nk; kt++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                               // K tile kt landed; everyone is done with the other stage
+            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+            const unsigned char* ls = smem + (kt & 1) * G::STAGE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+                for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const bf16x8_t*>(ls + offB[ks] + j * 2048);
+#pragma unroll
+                for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const bf16x8_t*>(ls + offA[ks] + i * 2048);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // every wave is done with both operand stages
+        const long em0 = m0, en0 = n0;
+        // ---- epilogue through LDS: each wave transposes its accumulators 16 rows a pass through a private window in
+        // stage 1 (padded f32 rows) and leaves 8 consecutive columns per lane.  Fast form (16-byte accessible out family,
+        // N % 8 == 0, at most one of mul/res, no gamma/rowscale): the bias is read once, and the mul/res operand of pass
+        // p+1 is requested before pass p is processed, so no global-load latency sits between the passes.
+        unsigned char* wl = smem + G::STAGE_BYTES + wave * G::EPI_WAVE;
+        constexpr int LPR = TN * 2;                        // lanes per row (8 columns each)
+        const bool fast = p.o_vec && (p.N & 7) == 0 && !(p.mul && p.res) && !p.gamma && !p.rowscale;   // block-uniform
+        auto wave_sync = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        if (fast) {
+            // lane -> fixed column group (so the bias is read once), rows r0 + RPI*it of the pass
+            constexpr int CG = TN == 4 ? 8 : 16, RPI = 64 / CG, NIT2 = 16 / RPI;
+            const TO* extra = (const TO*)(p.mul ? p.mul : p.res);
+            const int c8 = lane % CG, r0 = lane / CG;
+            const long mw = em0 + wr * (BM / 2), n = en0 + wc * (BN / 4) + c8 * 8;
+            const bool on = c8 < LPR && n < p.N;
+            float bias[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) bias[e] = (on && p.bias) ? p.bias[n + e] : 0.f;
+            Raw8<TO> nxt[NIT2];
+#pragma unroll
+            for (int it = 0; it < NIT2; it++) {
+                nxt[it] = Raw8<TO>{};
+                const long m = mw + r0 + RPI * it;
+                if (extra && on && m < p.M) nxt[it].load(extra + m * p.ldo + n);
+            }
+#pragma unroll
+            for (int pass = 0; pass < TM; pass++) {
+                Raw8<TO> cur[NIT2];
+#pragma unroll
+                for (int it = 0; it < NIT2; it++) {
+                    cur[it] = nxt[it];
+                    const long m = mw + (pass + 1) * 16 + r0 + RPI * it;
+                    if (pass + 1 < TM && extra && on && m < p.M) nxt[it].load(extra + m * p.ldo + n);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    *reinterpret_cast<f32x4_t*>(wl + fr * G::EPI_ROW + ((j * 4 + fg) << 4)) = acc[pass][j];
+                wave_sync();
+#pragma unroll
+                for (int it = 0; it < NIT2; it++) {
+                    const int row = r0 + RPI * it;
+                    const long m = mw + pass * 16 + row;
+                    if (on && m < p.M) {
+                        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(wl + row * G::EPI_ROW + c8 * 32);
+                        const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(wl + row * G::EPI_ROW + c8 * 32 + 16);
+                        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        float ex[8];
+                        cur[it].unpack(ex);
+                        const long off = m * p.ldo + n;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[e] += bias[e];
+                        if (p.pre) io8_store<TO>((TO*)p.pre + off, v);
+                        if (p.mul) {
+#pragma unroll
+                            for (int e = 0; e < 8; e++) v[e] *= act_bwd(p.act, ex[e]);
+                        } else if (p.act) {
+#pragma unroll
+                            for (int e = 0; e < 8; e++) v[e] = act_fwd(p.act, v[e]);
+                        }
+                        if (p.res) {
+#pragma unroll
+                            for (int e = 0; e < 8; e++) v[e] += ex[e];
+                        }
+                        io8_store<TO>((TO*)p.out + off, v);
+                    }
+                }
+                wave_sync();
+            }
+        } else {
+            const bool vec_all = p.o_vec != 0;
+#pragma unroll
+            for (int pass = 0; pass < TM; pass++) {
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    *reinterpret_cast<f32x4_t*>(wl + fr * G::EPI_ROW + ((j * 4 + fg) << 4)) = acc[pass][j];
+                wave_sync();
+#pragma unroll 1
+                for (int idx = lane; idx < 16 * LPR; idx += 64) {
+                    const int row = idx / LPR, c8 = idx % LPR;
+                    const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(wl + row * G::EPI_ROW + c8 * 32);
+                    const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(wl + row * G::EPI_ROW + c8 * 32 + 16);
+                    const long m = em0 + wr * (BM / 2) + pass * 16 + row, n = en0 + wc * (BN / 4) + c8 * 8;
+                    if (m < p.M && n < p.N) {
+                        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        gemm_epilogue8<TO>(p, v, m, n, vec_all && n + 8 <= p.N);
+                    }
+                }
+                wave_sync();
+            }
+        }
+    }
+}
+
+template <typename TO, int TM, int TN>
+int launch_big(const GemmP& p, hipStream_t st) {
+    typedef BigTile<TM, TN> G;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_big_k<TO, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) MM_FAIL(MM_ERR_LAUNCH, "gemm_big: cannot raise dynamic LDS to %d bytes: %s", G::LDS_BYTES, hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int tiles = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL((gemm_big_k<TO, TM, TN>), dim3((unsigned)tiles), dim3(512), G::LDS_BYTES, st, p);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+struct Shape { int tm, tn; };
+constexpr Shape kShapes[] = {{8, 4}, {7, 4}, {8, 5}, {7, 5}};
+
+// Estimated time of a tile shape: rounds of (at most one tile per CU) x (K steps x MFMA work + fixed prologue/epilogue).
+double shape_cost(const GemmP& p, Shape s) {
+    const long tiles = cdiv(p.M, 32 * s.tm) * cdiv(p.N, 64 * s.tn);
+    const long rounds = cdiv(tiles, kNumCU);
+    const double iter = 1.62 * (s.tm * s.tn) / 32.0;       // us per K step, measured on the 256x256 shape
+    return rounds * ((p.K / BK) * iter + 12.0);
+}
+}  // namespace
+
+// Is the large-tile kernel applicable (bf16, both operands K-contiguous, 16-byte aligned rows, K % 64 == 0) and worth it?
+bool gemm_big_applicable(const GemmP& p, int dtype, int a_kmajor, int b_kmajor, int splits) {
+    if (dtype != MM_BF16 || a_kmajor || b_kmajor || splits > 1 || p.partial) return false;
+    if (!p.a_vec || !p.b_vec || p.K % BK != 0) return false;
+    return (long)p.M * p.N >= 256L * 256 * 64;            // at least a quarter of the chip in 256x256 tiles
+}
+
+int gemm_big_launch(GemmP& p, int out_dtype, hipStream_t st) {
+    // 8-wide access to the out family: 16-byte aligned bases, row stride a multiple of 16 bytes
+    const int osz = out_dtype == MM_BF16 ? 2 : 4;
+    auto al = [&](const void* q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
+    p.o_vec = (p.ldo * osz) % 16 == 0 && al(p.out) && al(p.pre) && al(p.mul) && al(p.res);
+    int best = 0;
+    static const char* force = getenv("MM_GEMM_BIG_SHAPE");              // "0".."3": benchmark override
+    if (force) best = atoi(force) & 3;
+    else
+        for (int i = 1; i < 4; i++) if (shape_cost(p, kShapes[i]) < shape_cost(p, kShapes[best]) * 0.97) best = i;
+    const Shape s = kShapes[best];
+    p.tiles_m = (int)cdiv(p.M, 32 * s.tm); p.tiles_n = (int)cdiv(p.N, 64 * s.tn);
+#define GO_(TM_, TN_) return out_dtype == MM_BF16 ? launch_big<bf16, TM_, TN_>(p, st) : launch_big<float, TM_, TN_>(p, st)
+    switch (best) {
+        case 0: GO_(8, 4);
+        case 1: GO_(7, 4);
+        case 2: GO_(8, 5);
+        default: GO_(7, 5);
+    }
+#undef GO_
+}

@@ -213,25 +213,30 @@ class PrefixAttention(torch.autograd.Function):
 _operand_cache = {}
 
 
-def cached_operand(params, dtype) -> Tensor:
+def cached_operand(params, dtype, transpose: bool = False) -> Tensor:
     """Compute-dtype GEMM operand of one float32 master parameter, or of several stacked along dim 0 (the fused
     q/k/v projection).  Rebuilt only when a parameter's version counter or storage moves; OrthoGradAdamW bumps the
     counters of everything it updates, so the copy is made once per optimizer step instead of once per use."""
-    if len(params) == 1 and params[0].dtype == dtype:
+    if len(params) == 1 and params[0].dtype == dtype and not transpose:
         return params[0].detach()
-    key = tuple(id(p) for p in params) + (dtype,)
+    key = tuple(id(p) for p in params) + (dtype, transpose)
     stamp = tuple((p._version, p.data_ptr()) for p in params)
     ent = _operand_cache.get(key)
     if ent is not None and ent[0] == stamp and all(r() is p for r, p in zip(ent[2], params)):
         return ent[1]
     shape = (sum(p.shape[0] for p in params),) + tuple(params[0].shape[1:])
+    if transpose:                      # [in, out] copy: makes dX = dY . W a K-contiguous (NT) product as well
+        shape = (shape[1], shape[0])
     dev = params[0].device
     buf = ent[1] if ent is not None and tuple(ent[1].shape) == shape and ent[1].device == dev else \
         torch.empty(shape, dtype=dtype, device=dev)
     off = 0
     with torch.no_grad():
         for p in params:
-            buf[off: off + p.shape[0]].copy_(p)
+            if transpose:
+                ops.cast_transpose(p.detach(), buf[:, off: off + p.shape[0]])
+            else:
+                buf[off: off + p.shape[0]].copy_(p)
             off += p.shape[0]
     _operand_cache[key] = (stamp, buf, tuple(weakref.ref(p) for p in params))
     return buf
@@ -244,6 +249,15 @@ def _mm_f32(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
     if out is not None:
         return torch.mm(a, b, out_dtype=torch.float32, out=out)
     return torch.mm(a, b, out_dtype=torch.float32)
+
+
+def _linear_res(x2: Tensor, w: Tensor, b: Tensor, res: Tensor) -> Tensor:
+    """res + x2 W^T + b.  bf16: the large-tile libmmhip GEMM with bias and residual fused in its epilogue (these are
+    the N = d_model products, where its tile choice beats the library's); f32: library GEMM + in-place add."""
+    dt = x2.dtype
+    if dt == torch.bfloat16:
+        return ops.gemm(x2, cached_operand((w,), dt), x2.shape[0], w.shape[0], w.shape[1], bias=b.detach(), res=res)
+    return torch.addmm(b.detach(), x2, w.detach().t()).add_(res)
 
 
 def _weight_grad(p: Tensor, dy2: Tensor, x2: Tensor) -> Optional[Tensor]:
@@ -305,11 +319,11 @@ class DecoderLayer(torch.autograd.Function):
         ops.rope_inplace(qkv.view(B, S, 3 * D)[:, :, :2 * D], 2 * H, rot, cos_t, sin_t)      # q and k in one launch
         o, lse = ops.prefix_attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], H, 0, prompt_len, cos_t, sin_t, stablemax,
                                      save_lse=train)
-        x1 = torch.addmm(cached_operand((ob,), dt), o.view(M, D), cached_operand((ow,), dt).t()).add_(x.view(M, D))
+        x1 = _linear_res(o.view(M, D), ow, ob, x.view(M, D))
         xf, mean2, rstd2 = ops.layernorm_fwd(x1, ln2w.detach(), ln2b.detach(), save_stats=train)
         h = torch.addmm(cached_operand((b1,), dt), xf, cached_operand((w1,), dt).t())
         a = ops.relu2_fwd(h)
-        out = torch.addmm(cached_operand((b2,), dt), a, cached_operand((w2,), dt).t()).add_(x1)
+        out = _linear_res(a, w2, b2, x1)
         if train:
             ctx.save_for_backward(x, mean1, rstd1, xa, qkv, o, lse, x1, mean2, rstd2, xf, h, a, cos_t, sin_t,
                                   ln1w, qw, kw, vw, ow, ln2w, w1, w2)
@@ -333,7 +347,10 @@ class DecoderLayer(torch.autograd.Function):
         ops.relu2_bwd_(h, dh)
         db1 = ops.colsum(dh, M, F4)
         dw1 = _weight_grad(w1, dh, xf)
-        dxf = torch.mm(dh, cached_operand((w1,), dt))
+        if dt == torch.bfloat16:         # N = d_model, K = d_ffn: NT product on the transposed operand copy
+            dxf = ops.gemm(dh, cached_operand((w1,), dt, transpose=True), M, D, F4)
+        else:
+            dxf = torch.mm(dh, w1.detach())
         dx1, dln2w, dln2b = ops.layernorm_bwd(x1, dxf, dout, ln2w.detach(), mean2, rstd2)      # + residual gradient
         # ---- attention
         dbo = ops.colsum(dx1, M, D)

@@ -346,6 +346,17 @@ def relu2_bwd_(h: Tensor, da: Tensor) -> Tensor:
     return da
 
 
+def cast_transpose(w: Tensor, out: Tensor) -> Tensor:
+    """out[:, :] (view [C, R] with unit inner stride, bf16 or f32) = w[R, C].T in out's dtype."""
+    _f32(w, "w")
+    R, Cc = w.shape
+    if tuple(out.shape) != (Cc, R) or out.stride(1) != 1 or not out.is_cuda:
+        raise RuntimeError("cast_transpose: out must be a GPU [C, R] view with unit inner stride")
+    L.check(L.lib().mm_cast_transpose(L.ptr(w), L.ptr(out), R, Cc, out.stride(0), L.dtype_code(out), L.cur_stream()),
+            "mm_cast_transpose")
+    return out
+
+
 def rope_inplace(x: Tensor, H: int, rot: int, cos_t: Tensor, sin_t: Tensor, inverse: bool = False) -> None:
     """x: [B,S,E] view (unit inner stride, batch stride S*row stride), rotated in place."""
     if rot == 0:

@@ -214,6 +214,48 @@ def test_gemm_epilogues(dtype):
     assert torch.equal(o2, o3)                                 # bitwise reproducible
 
 
+@pytest.mark.parametrize("M,N,K", [(2100, 2052, 192), (4096, 1024, 64), (1111, 4100, 320), (2304, 2304, 1600),
+                                   (10080, 1600, 128), (13056, 1596, 64), (10080, 1280, 128)])   # the last three pick 224x320, 256x320, 224x256 tiles
+def test_gemm_large_tile(M, N, K):
+    """The 256x256 global->LDS-DMA kernel (bf16, K-contiguous operands, K % 64 == 0): ragged M / N edges, every
+    epilogue, both output types; compared with the exact product of the bf16 operands."""
+    from multimodal_amd import ops
+    d = _dev()
+    a = _rand(M, K, seed=1).to(torch.bfloat16); w = _rand(N, K, seed=2, scale=0.3).to(torch.bfloat16)
+    ref = (a.double() @ w.double().t())
+    scale = (a.double().abs() @ w.double().abs().t()).max().item()
+    out = ops.gemm(a.to(d), w.to(d), M, N, K, out_dtype=torch.float32)
+    assert (out.double().cpu() - ref).abs().max().item() <= 2e-6 * scale
+    bias = _rand(N, seed=3, scale=0.2)
+    h = ref.float() + bias
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=d)
+    res = _rand(M, N, seed=5).to(torch.bfloat16)
+    out = ops.gemm(a.to(d), w.to(d), M, N, K, bias=bias.to(d), pre=pre, act=ops.ACT_RELU2)
+    assert rel_err(pre.float().cpu(), h) < TOL[torch.bfloat16]
+    assert rel_err(out.float().cpu(), F.relu(h).square()) < TOL[torch.bfloat16]
+    out = ops.gemm(a.to(d), w.to(d), M, N, K, bias=bias.to(d), res=res.to(d))
+    assert rel_err(out.float().cpu(), h + res.float()) < TOL[torch.bfloat16]
+    hp = _rand(M, N, seed=6, scale=2.0).to(torch.bfloat16)
+    out = ops.gemm(a.to(d), w.to(d), M, N, K, mul=hp.to(d), act=ops.ACT_RELU2)
+    assert rel_err(out.float().cpu(), ref.float() * 2 * F.relu(hp.float())) < TOL[torch.bfloat16]
+
+
+def test_cast_transpose_and_relu2():
+    from multimodal_amd import ops
+    d = _dev()
+    w = _rand(130, 77, seed=1).to(d)
+    for dt in (torch.bfloat16, torch.float32):
+        out = torch.zeros(77, 3 * 130, dtype=dt, device=d)
+        ops.cast_transpose(w, out[:, 130:260])
+        assert torch.equal(out[:, 130:260], w.t().to(dt)) and out[:, :130].abs().sum() == 0 and out[:, 260:].abs().sum() == 0
+        h = _rand(37, 101, seed=2, scale=2.0).to(dt).to(d)
+        a = ops.relu2_fwd(h)
+        assert torch.equal(a, torch.relu(h.float()).square().to(dt))
+        da = _rand(37, 101, seed=3).to(dt).to(d)
+        ref = (da.float() * 2 * torch.relu(h.float())).to(dt)
+        assert torch.equal(ops.relu2_bwd_(h, da.clone()), ref)
+
+
 def test_colsum():
     from multimodal_amd import ops
     for dtype in (torch.float32, torch.bfloat16):
