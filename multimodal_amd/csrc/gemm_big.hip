@@ -47,8 +47,106 @@ template <int TM, int TN> struct BigTile {
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
     static constexpr int PIECES = (BM + BN) / 8;                       // 1 KiB DMA pieces (8 rows) per stage
     static constexpr int PPW = (PIECES + 7) / 8;                       // pieces per wave (the last may be absent)
-    static_assert(8 * EPI_WAVE <= STAGE_BYTES, "epilogue windows must fit in stage 1");
 };
+
+// ---- epilogue through LDS: a wave transposes its TM x TN accumulator tiles 16 rows a pass through a private window
+// `wl` (padded f32 rows of EPI_ROW bytes) and leaves 8 consecutive columns per lane.  Fast form (16-byte accessible out
+// family, N % 8 == 0, at most one of mul/res, no gamma/rowscale): the bias is read once, and the mul/res operand of
+// pass p+1 is requested before pass p is processed, so no global-load latency sits between the passes.
+// mw, nw: first row / column of the wave's tile.
+template <typename TO, int TM, int TN, int EPI_ROW>
+__device__ __forceinline__ void big_epilogue(const GemmP& p, f32x4_t (&acc)[TM][TN], unsigned char* wl, long mw, long nw, int lane) {
+    const int fr = lane & 15, fg = lane >> 4;
+    constexpr int LPR = TN * 2;                        // lanes per row (8 columns each)
+    const bool fast = p.o_vec && (p.N & 7) == 0 && !(p.mul && p.res) && !p.gamma && !p.rowscale;   // block-uniform
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if (fast) {
+        // lane -> fixed column group (so the bias is read once), rows r0 + RPI*it of the pass
+        constexpr int CG = TN == 4 ? 8 : 16, RPI = 64 / CG, NIT2 = 16 / RPI;
+        const TO* extra = (const TO*)(p.mul ? p.mul : p.res);
+        const int c8 = lane % CG, r0 = lane / CG;
+        const long n = nw + c8 * 8;
+        const bool on = c8 < LPR && n < p.N;
+        float bias[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) bias[e] = (on && p.bias) ? p.bias[n + e] : 0.f;
+        Raw8<TO> nxt[NIT2];
+#pragma unroll
+        for (int it = 0; it < NIT2; it++) {
+            nxt[it] = Raw8<TO>{};
+            const long m = mw + r0 + RPI * it;
+            if (extra && on && m < p.M) nxt[it].load(extra + m * p.ldo + n);
+        }
+#pragma unroll
+        for (int pass = 0; pass < TM; pass++) {
+            Raw8<TO> cur[NIT2];
+#pragma unroll
+            for (int it = 0; it < NIT2; it++) {
+                cur[it] = nxt[it];
+                const long m = mw + (pass + 1) * 16 + r0 + RPI * it;
+                if (pass + 1 < TM && extra && on && m < p.M) nxt[it].load(extra + m * p.ldo + n);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                *reinterpret_cast<f32x4_t*>(wl + fr * EPI_ROW + ((j * 4 + fg) << 4)) = acc[pass][j];
+            wave_sync();
+#pragma unroll
+            for (int it = 0; it < NIT2; it++) {
+                const int row = r0 + RPI * it;
+                const long m = mw + pass * 16 + row;
+                if (on && m < p.M) {
+                    const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(wl + row * EPI_ROW + c8 * 32);
+                    const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(wl + row * EPI_ROW + c8 * 32 + 16);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    float ex[8];
+                    cur[it].unpack(ex);
+                    const long off = m * p.ldo + n;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] += bias[e];
+                    if (p.pre) io8_store<TO>((TO*)p.pre + off, v);
+                    if (p.mul) {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[e] *= act_bwd(p.act, ex[e]);
+                    } else if (p.act) {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[e] = act_fwd(p.act, v[e]);
+                    }
+                    if (p.res) {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[e] += ex[e];
+                    }
+                    io8_store<TO>((TO*)p.out + off, v);
+                }
+            }
+            wave_sync();
+        }
+    } else {
+        const bool vec_all = p.o_vec != 0;
+#pragma unroll
+        for (int pass = 0; pass < TM; pass++) {
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                *reinterpret_cast<f32x4_t*>(wl + fr * EPI_ROW + ((j * 4 + fg) << 4)) = acc[pass][j];
+            wave_sync();
+#pragma unroll 1
+            for (int idx = lane; idx < 16 * LPR; idx += 64) {
+                const int row = idx / LPR, c8 = idx % LPR;
+                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(wl + row * EPI_ROW + c8 * 32);
+                const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(wl + row * EPI_ROW + c8 * 32 + 16);
+                const long m = mw + pass * 16 + row, n = nw + c8 * 8;
+                if (m < p.M && n < p.N) {
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    gemm_epilogue8<TO>(p, v, m, n, vec_all && n + 8 <= p.N);
+                }
+            }
+            wave_sync();
+        }
+    }
+}
 
 template <typename TO, int TM, int TN>
 __global__ __launch_bounds__(512, 1) void gemm_big_k(const GemmP p) {
@@ -119,116 +217,24 @@ __global__ __launch_bounds__(512, 1) void gemm_big_k(const GemmP p) {
             __syncthreads();                               // K tile kt landed; everyone is done with the other stage
             if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
             const unsigned char* ls = smem + (kt & 1) * G::STAGE_BYTES;
+            {
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                bf16x8_t fa[TM], fb[TN];
+                for (int ks = 0; ks < 2; ks++) {
+                    bf16x8_t fa[TM], fb[TN];
 #pragma unroll
-                for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const bf16x8_t*>(ls + offB[ks] + j * 2048);
+                    for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const bf16x8_t*>(ls + offB[ks] + j * 2048);
 #pragma unroll
-                for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const bf16x8_t*>(ls + offA[ks] + i * 2048);
+                    for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const bf16x8_t*>(ls + offA[ks] + i * 2048);
 #pragma unroll
-                for (int i = 0; i < TM; i++)
+                    for (int i = 0; i < TM; i++)
 #pragma unroll
-                    for (int j = 0; j < TN; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                }
             }
         }
         __syncthreads();                                   // every wave is done with both operand stages
-        const long em0 = m0, en0 = n0;
-        // ---- epilogue through LDS: each wave transposes its accumulators 16 rows a pass through a private window in
-        // stage 1 (padded f32 rows) and leaves 8 consecutive columns per lane.  Fast form (16-byte accessible out family,
-        // N % 8 == 0, at most one of mul/res, no gamma/rowscale): the bias is read once, and the mul/res operand of pass
-        // p+1 is requested before pass p is processed, so no global-load latency sits between the passes.
-        unsigned char* wl = smem + G::STAGE_BYTES + wave * G::EPI_WAVE;
-        constexpr int LPR = TN * 2;                        // lanes per row (8 columns each)
-        const bool fast = p.o_vec && (p.N & 7) == 0 && !(p.mul && p.res) && !p.gamma && !p.rowscale;   // block-uniform
-        auto wave_sync = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
-        if (fast) {
-            // lane -> fixed column group (so the bias is read once), rows r0 + RPI*it of the pass
-            constexpr int CG = TN == 4 ? 8 : 16, RPI = 64 / CG, NIT2 = 16 / RPI;
-            const TO* extra = (const TO*)(p.mul ? p.mul : p.res);
-            const int c8 = lane % CG, r0 = lane / CG;
-            const long mw = em0 + wr * (BM / 2), n = en0 + wc * (BN / 4) + c8 * 8;
-            const bool on = c8 < LPR && n < p.N;
-            float bias[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) bias[e] = (on && p.bias) ? p.bias[n + e] : 0.f;
-            Raw8<TO> nxt[NIT2];
-#pragma unroll
-            for (int it = 0; it < NIT2; it++) {
-                nxt[it] = Raw8<TO>{};
-                const long m = mw + r0 + RPI * it;
-                if (extra && on && m < p.M) nxt[it].load(extra + m * p.ldo + n);
-            }
-#pragma unroll
-            for (int pass = 0; pass < TM; pass++) {
-                Raw8<TO> cur[NIT2];
-#pragma unroll
-                for (int it = 0; it < NIT2; it++) {
-                    cur[it] = nxt[it];
-                    const long m = mw + (pass + 1) * 16 + r0 + RPI * it;
-                    if (pass + 1 < TM && extra && on && m < p.M) nxt[it].load(extra + m * p.ldo + n);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-                    *reinterpret_cast<f32x4_t*>(wl + fr * G::EPI_ROW + ((j * 4 + fg) << 4)) = acc[pass][j];
-                wave_sync();
-#pragma unroll
-                for (int it = 0; it < NIT2; it++) {
-                    const int row = r0 + RPI * it;
-                    const long m = mw + pass * 16 + row;
-                    if (on && m < p.M) {
-                        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(wl + row * G::EPI_ROW + c8 * 32);
-                        const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(wl + row * G::EPI_ROW + c8 * 32 + 16);
-                        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        float ex[8];
-                        cur[it].unpack(ex);
-                        const long off = m * p.ldo + n;
-#pragma unroll
-                        for (int e = 0; e < 8; e++) v[e] += bias[e];
-                        if (p.pre) io8_store<TO>((TO*)p.pre + off, v);
-                        if (p.mul) {
-#pragma unroll
-                            for (int e = 0; e < 8; e++) v[e] *= act_bwd(p.act, ex[e]);
-                        } else if (p.act) {
-#pragma unroll
-                            for (int e = 0; e < 8; e++) v[e] = act_fwd(p.act, v[e]);
-                        }
-                        if (p.res) {
-#pragma unroll
-                            for (int e = 0; e < 8; e++) v[e] += ex[e];
-                        }
-                        io8_store<TO>((TO*)p.out + off, v);
-                    }
-                }
-                wave_sync();
-            }
-        } else {
-            const bool vec_all = p.o_vec != 0;
-#pragma unroll
-            for (int pass = 0; pass < TM; pass++) {
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-                    *reinterpret_cast<f32x4_t*>(wl + fr * G::EPI_ROW + ((j * 4 + fg) << 4)) = acc[pass][j];
-                wave_sync();
-#pragma unroll 1
-                for (int idx = lane; idx < 16 * LPR; idx += 64) {
-                    const int row = idx / LPR, c8 = idx % LPR;
-                    const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(wl + row * G::EPI_ROW + c8 * 32);
-                    const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(wl + row * G::EPI_ROW + c8 * 32 + 16);
-                    const long m = em0 + wr * (BM / 2) + pass * 16 + row, n = en0 + wc * (BN / 4) + c8 * 8;
-                    if (m < p.M && n < p.N) {
-                        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        gemm_epilogue8<TO>(p, v, m, n, vec_all && n + 8 <= p.N);
-                    }
-                }
-                wave_sync();
-            }
-        }
+        big_epilogue<TO, TM, TN, G::EPI_ROW>(p, acc, smem + G::STAGE_BYTES + wave * G::EPI_WAVE, m0 + wr * (BM / 2), n0 + wc * (BN / 4), lane);
     }
 }
 
