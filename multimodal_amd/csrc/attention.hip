@@ -1075,6 +1075,281 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dkv4_k(const AttnP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 backward fast path (q,k already rotated: rot == 0; 8-byte aligned rows), same structure as
+// prefix_attn_fwd2_k: stationary fragments straight from global memory, streamed tiles of 64 rows (32 for d > 256)
+// held in registers and prefetched one tile ahead, gradients stored from the accumulators (a lane owns 4 consecutive
+// head-dim columns of one row): no LDS prologue / epilogue passes.
+// ------------------------------------------------------------------------------------------------
+template <int DP, int KT, bool STABLE>
+__global__ __launch_bounds__(256) void prefix_attn_bwd_dq5_k(const AttnP p) {
+    typedef bf16 T;
+    constexpr int PITCH = DP + 8;
+    constexpr int NKS = DP / 32, NDV = DP / 16, NT16 = KT / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* lk = reinterpret_cast<T*>(smem);
+    T* lv = lk + KT * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = blockIdx.x * 64;
+    const long head_off = (long)b * p.S * p.ld + (long)h * p.d;
+    const T* qg = (const T*)p.q + head_off;
+    const T* kg = (const T*)p.k + head_off;
+    const T* vg = (const T*)p.v + head_off;
+    const T* dog = (const T*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d;
+    const int qw0 = q0 + 16 * wave;
+    const int qi = qw0 + fr;
+    const bool qok = qi < p.S;
+    auto key_end = [&](int qlo, int qhi) {
+        int e = min(qhi, p.S - 1) + 1;
+        if (qlo < p.P) e = max(e, p.P);
+        return min(e, p.S);
+    };
+    const int kend_blk = key_end(q0, q0 + 63);
+    const int kend_w = (qw0 < p.S) ? key_end(qw0, qw0 + 15) : 0;
+
+    TileRegs<DP, KT> rk, rv;
+    tile_load<DP, KT>(rk, kg, p.ld, 0, p.S, p.d);
+    tile_load<DP, KT>(rv, vg, p.ld, 0, p.S, p.d);
+    bf16x8_t qf[NKS], gf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) {
+        qf[ks] = frag_load(qg, p.ld, qi, ks * 32 + fg * 8, p.S, p.d);
+        gf[ks] = frag_load(dog, p.ld_o, qi, ks * 32 + fg * 8, p.S, p.d);
+    }
+    const long stat = ((long)b * p.H + h) * p.S + (qok ? qi : 0);
+    const float lse = p.lse[stat], dlt = p.delta[stat];
+    const float invL = STABLE ? 1.0f / fmaxf(lse, 1e-9f) : 0.f;
+
+    f32x4_t dqa[NDV];
+#pragma unroll
+    for (int n = 0; n < NDV; n++) dqa[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    typedef bf16x4_t __attribute__((address_space(3))) * lds4p;
+    const int qq = fr >> 2, pp = fr & 3;
+
+    for (int k0 = 0; k0 < kend_blk; k0 += KT) {
+        tile_store<DP, KT>(rk, lk, PITCH);
+        tile_store<DP, KT>(rv, lv, PITCH);
+        __syncthreads();
+        if (k0 + KT < kend_blk) {
+            tile_load<DP, KT>(rk, kg, p.ld, k0 + KT, p.S, p.d);
+            tile_load<DP, KT>(rv, vg, p.ld, k0 + KT, p.S, p.d);
+        }
+        if (k0 < kend_w) {
+            f32x4_t sa[NT16], da[NT16];
+#pragma unroll
+            for (int t = 0; t < NT16; t++) {
+                sa[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; da[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ks++) {
+                    const int off = ks * 32 + fg * 8;
+                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&lk[(16 * t + fr) * PITCH + off]);
+                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(&lv[(16 * t + fr) * PITCH + off]);
+                    sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sa[t], 0, 0, 0);
+                    da[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[ks], da[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < KT / 32; kk++) {
+                bf16x8_t dsf;
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int t = 2 * kk + tt;
+                        const int kj = k0 + 16 * t + 4 * fg + r;
+                        const float x = sa[t][r] * p.scale;
+                        float ds = 0.f;
+                        if (qok && attn_allowed(qi, kj, p.P, p.S)) {
+                            if (STABLE) { const float sx = stable_s_f(x); ds = (da[t][r] - dlt) * invL * (x < 0.f ? sx * sx : 1.f); }
+                            else { const float pr = __expf(x - lse); ds = pr * (da[t][r] - dlt); }
+                        }
+                        dsf[4 * tt + r] = (short)f2bf(ds);
+                    }
+                if (k0 + 32 * kk < kend_w) {             // wave-uniform: later keys are masked for every query here
+#pragma unroll
+                    for (int n = 0; n < NDV; n++) {
+                        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lk[(32 * kk + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lk[(32 * kk + 16 + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                        const bf16x8_t kt = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        dqa[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf, dqa[n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (qok) {
+        T* dq = (T*)p.dq + ((long)b * p.S + qi) * p.ld_d + (long)h * p.d;
+#pragma unroll
+        for (int n = 0; n < NDV; n++) {
+            const int dv = 16 * n + 4 * fg;
+            if (dv < p.d) {
+                const float o4[4] = {dqa[n][0] * p.scale, dqa[n][1] * p.scale, dqa[n][2] * p.scale, dqa[n][3] * p.scale};
+                VecIO<T, 4>::store(dq + dv, o4);
+            }
+        }
+    }
+}
+
+template <int DP, int QT, bool STABLE>
+__global__ __launch_bounds__(256) void prefix_attn_bwd_dkv5_k(const AttnP p) {
+    typedef bf16 T;
+    constexpr int PITCH = DP + 8;
+    constexpr int NKS = DP / 32, NDV = DP / 16, NT16 = QT / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* lq = reinterpret_cast<T*>(smem);
+    T* ldo = lq + QT * PITCH;
+    float* lstat = reinterpret_cast<float*>(ldo + QT * PITCH);       // [2][QT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int kb0 = blockIdx.x * 64;
+    const long head_off = (long)b * p.S * p.ld + (long)h * p.d;
+    const T* qg = (const T*)p.q + head_off;
+    const T* kg = (const T*)p.k + head_off;
+    const T* vg = (const T*)p.v + head_off;
+    const T* dog = (const T*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d;
+    const int kw0 = kb0 + 16 * wave;
+    const int kj = kw0 + fr;
+    const long statbase = ((long)b * p.H + h) * p.S;
+    const int qstart_blk = (kb0 < p.P) ? 0 : (kb0 / QT) * QT;
+    const int qstart_w = (kw0 < p.P) ? 0 : kw0;        // first query that can see any key of this wave
+    const bool wave_live = kw0 < p.S;
+
+    TileRegs<DP, QT> rq, rg;
+    tile_load<DP, QT>(rq, qg, p.ld, qstart_blk, p.S, p.d);
+    tile_load<DP, QT>(rg, dog, p.ld_o, qstart_blk, p.S, p.d);
+    bf16x8_t kf[NKS], vf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) {
+        kf[ks] = frag_load(kg, p.ld, kj, ks * 32 + fg * 8, p.S, p.d);
+        vf[ks] = frag_load(vg, p.ld, kj, ks * 32 + fg * 8, p.S, p.d);
+    }
+    float st_l = 1.f, st_d = 0.f;                       // this thread's slot of the next tile's row statistics
+    if (tid < QT) {
+        const int qi = qstart_blk + tid;
+        st_l = qi < p.S ? p.lse[statbase + qi] : 1.f; st_d = qi < p.S ? p.delta[statbase + qi] : 0.f;
+    }
+
+    f32x4_t dka[NDV], dva[NDV];
+#pragma unroll
+    for (int n = 0; n < NDV; n++) { dka[n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dva[n] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    typedef bf16x4_t __attribute__((address_space(3))) * lds4p;
+    const int qq = fr >> 2, pp = fr & 3;
+
+    for (int q0 = qstart_blk; q0 < p.S; q0 += QT) {
+        tile_store<DP, QT>(rq, lq, PITCH);
+        tile_store<DP, QT>(rg, ldo, PITCH);
+        if (tid < QT) { lstat[tid] = st_l; lstat[QT + tid] = st_d; }
+        __syncthreads();
+        if (q0 + QT < p.S) {
+            tile_load<DP, QT>(rq, qg, p.ld, q0 + QT, p.S, p.d);
+            tile_load<DP, QT>(rg, dog, p.ld_o, q0 + QT, p.S, p.d);
+            if (tid < QT) {
+                const int qi = q0 + QT + tid;
+                st_l = qi < p.S ? p.lse[statbase + qi] : 1.f; st_d = qi < p.S ? p.delta[statbase + qi] : 0.f;
+            }
+        }
+        if (wave_live && q0 + QT > qstart_w) {
+            f32x4_t sa[NT16], da[NT16];
+#pragma unroll
+            for (int t = 0; t < NT16; t++) {
+                sa[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; da[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ks++) {
+                    const int off = ks * 32 + fg * 8;
+                    const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(&lq[(16 * t + fr) * PITCH + off]);
+                    const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(&ldo[(16 * t + fr) * PITCH + off]);
+                    sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], sa[t], 0, 0, 0);
+                    da[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf[ks], da[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < QT / 32; kk++) {
+                bf16x8_t pf, dsf;
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int t = 2 * kk + tt;
+                        const int ql = 16 * t + 4 * fg + r;
+                        const int qi = q0 + ql;
+                        const float x = sa[t][r] * p.scale;
+                        float pr = 0.f, ds = 0.f;
+                        if (qi < p.S && attn_allowed(qi, kj, p.P, p.S)) {
+                            const float lse = lstat[ql], dlt = lstat[QT + ql];
+                            if (STABLE) {
+                                const float sx = stable_s_f(x), invL = 1.0f / fmaxf(lse, 1e-9f);
+                                pr = sx * invL; ds = (da[t][r] - dlt) * invL * (x < 0.f ? sx * sx : 1.f);
+                            } else { pr = __expf(x - lse); ds = pr * (da[t][r] - dlt); }
+                        }
+                        pf[4 * tt + r] = (short)f2bf(pr); dsf[4 * tt + r] = (short)f2bf(ds);
+                    }
+                if (q0 + 32 * kk + 32 > qstart_w) {      // wave-uniform: earlier queries see none of this wave's keys
+#pragma unroll
+                    for (int n = 0; n < NDV; n++) {
+                        const bf16x4_t glo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&ldo[(32 * kk + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                        const bf16x4_t ghi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&ldo[(32 * kk + 16 + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                        const bf16x8_t gt = bf16x8_t{glo[0], glo[1], glo[2], glo[3], ghi[0], ghi[1], ghi[2], ghi[3]};
+                        dva[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf, dva[n], 0, 0, 0);
+                        const bf16x4_t qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lq[(32 * kk + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                        const bf16x4_t qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(&lq[(32 * kk + 16 + 4 * fg + qq) * PITCH + 16 * n + 4 * pp]));
+                        const bf16x8_t qt = bf16x8_t{qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+                        dka[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf, dka[n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (kj < p.S) {
+        T* dk = (T*)p.dk + ((long)b * p.S + kj) * p.ld_d + (long)h * p.d;
+        T* dv = (T*)p.dv + ((long)b * p.S + kj) * p.ld_d + (long)h * p.d;
+#pragma unroll
+        for (int n = 0; n < NDV; n++) {
+            const int c = 16 * n + 4 * fg;
+            if (c < p.d) {
+                const float k4[4] = {dka[n][0] * p.scale, dka[n][1] * p.scale, dka[n][2] * p.scale, dka[n][3] * p.scale};
+                const float v4[4] = {dva[n][0], dva[n][1], dva[n][2], dva[n][3]};
+                VecIO<T, 4>::store(dk + c, k4);
+                VecIO<T, 4>::store(dv + c, v4);
+            }
+        }
+    }
+}
+
+template <int DP, int KT>
+static int bwd_launch5(const AttnP& p, int mode, hipStream_t st) {
+    constexpr int PITCH = DP + 8;
+    const size_t lds = (size_t)2 * KT * PITCH * 2 + 2 * KT * sizeof(float);
+    const dim3 grid((unsigned)cdiv(p.S, 64), (unsigned)(p.B * p.H));
+#define SETATTR_(K_) if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    if (mode == MM_ATTN_STABLEMAX) {
+        SETATTR_((prefix_attn_bwd_dq5_k<DP, KT, true>));
+        hipLaunchKernelGGL((prefix_attn_bwd_dq5_k<DP, KT, true>), grid, dim3(256), lds, st, p);
+        SETATTR_((prefix_attn_bwd_dkv5_k<DP, KT, true>));
+        hipLaunchKernelGGL((prefix_attn_bwd_dkv5_k<DP, KT, true>), grid, dim3(256), lds, st, p);
+    } else {
+        SETATTR_((prefix_attn_bwd_dq5_k<DP, KT, false>));
+        hipLaunchKernelGGL((prefix_attn_bwd_dq5_k<DP, KT, false>), grid, dim3(256), lds, st, p);
+        SETATTR_((prefix_attn_bwd_dkv5_k<DP, KT, false>));
+        hipLaunchKernelGGL((prefix_attn_bwd_dkv5_k<DP, KT, false>), grid, dim3(256), lds, st, p);
+    }
+#undef SETATTR_
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+static int bwd_dispatch5(const AttnP& p, int mode, hipStream_t st) {
+    const int d = p.d;
+    if (d <= 32) return bwd_launch5<32, 64>(p, mode, st);
+    if (d <= 64) return bwd_launch5<64, 64>(p, mode, st);
+    if (d <= 128) return bwd_launch5<128, 64>(p, mode, st);
+    if (d <= 192) return bwd_launch5<192, 64>(p, mode, st);
+    MM_FAIL(MM_ERR_UNSUPPORTED, "prefix_attn_bwd: head_dim %d > 512", d);
+}
+
 template <int DP>
 static int bwd_launch4(const AttnP& p, int mode, hipStream_t st) {
     constexpr int PITCH = DP + 8;
@@ -1170,6 +1445,10 @@ extern "C" int mm_prefix_attn_bwd(const void* q, const void* k, const void* v, c
     hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, o, d_o, (float*)workspace, rows, (int)H, (int)S,
                        (int)d, (long)(H * d), (long)(H * d), dtype == MM_BF16 ? 1 : 0);
     MM_LAUNCH_CHECK();
+    static const bool force_generic = getenv("MM_ATTN_GENERIC") != nullptr;     // A/B switch for debugging
+    const bool al8 = (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8) == 0 && ld_dqkv % 4 == 0;
+    // measured: the fast form wins up to d = 192 (1.05-1.5x); beyond that its register footprint loses to the staged kernels
+    if (!force_generic && dtype == MM_BF16 && rot == 0 && p.vec_ok && al8 && d <= 192) return bwd_dispatch5(p, mode, st);
     return dtype == MM_BF16 ? bwd_dispatch4(p, mode, st) : bwd_dispatch<float>(p, mode, st);
 }
 
