@@ -26,6 +26,7 @@ CONFIGS = {
     "real_config_mup": dict(E=2048, H=4, L=8, sm=True, max_seq=95, max_nmr=190, max_mem=32),
 }
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide)
 
 
 def build_model(c, device, seed=0):
@@ -67,10 +68,41 @@ def k1_roofline(device, dtype=torch.float32, B=8192, C=64, Ln=250, iters=20):
     t = s.elapsed_time(e) / iters * 1e-3
     nbytes = B * C * Ln * 2 * x.element_size()
     ach = nbytes / t / 1e9
+    # HBM bytes per launch from the PMC passes (cannot be collected live: rocprofv3 --pmc runs benchmarks/k1_pmc.py on
+    # this same shape; benchmarks/pmc_summary.py applies the gfx950 FETCH_SIZE x2 correction) -- fp32 shape only
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
+    if dtype == torch.float32 and (B, C, Ln) == (8192, 64, 250) and os.path.exists(pmc):
+        with open(pmc) as fh:
+            traffic = int(json.load(fh)["traffic_bytes_per_launch"])
     return {"kernel": "dwconv7_ln_fwd_strip", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "launch_us": round(t * 1e6, 2),
+            "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "launch_us": round(t * 1e6, 2),
             "shape": {"B": B, "C": C, "L": Ln, "dtype": str(dtype).replace("torch.", "")},
             "algorithmic_bytes_per_launch": nbytes}
+
+
+def gemm_roofline(device, M=10080, N=1600, K=6400, iters=20):
+    """The decoder's d_ffn -> d_model projection on the large-tile MFMA kernel (bias + residual fused): 2*M*N*K flops
+    over the average launch time (HIP events on the launch stream) against the dense bf16 MFMA peak."""
+    from multimodal_amd import ops
+    a = (torch.rand(M, K, device=device) * 2 - 1).to(torch.bfloat16)
+    w = (torch.rand(N, K, device=device) * 2 - 1).to(torch.bfloat16)
+    bias = torch.zeros(N, device=device)
+    res = torch.zeros(M, N, device=device, dtype=torch.bfloat16)
+    for _ in range(3):
+        ops.gemm(a, w, M, N, K, bias=bias, res=res)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        ops.gemm(a, w, M, N, K, bias=bias, res=res)
+    e.record()
+    torch.cuda.synchronize()
+    t = s.elapsed_time(e) / iters * 1e-3
+    ach = 2.0 * M * N * K / t / 1e12
+    return {"kernel": "gemm_big_k<bf16,7,5>", "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "launch_us": round(t * 1e6, 2),
+            "shape": {"M": M, "N": N, "K": K, "dtype": "bfloat16", "epilogue": "bias+residual"}}
 
 
 def greedy_bench(device, world, rank):
@@ -91,7 +123,7 @@ def greedy_bench(device, world, rank):
             "config": "local_config_nocat", "dtype": "bf16", "kv_cache": True, "seconds": round(dt, 4)}
 
 
-def cpu_baseline(c, sample_b=2):
+def cpu_baseline(c, sample_b=16):
     """The CPU oracle (oracle/restate.py, pinned against the reference) timed on the host cores: one train step
     (forward + CE + backward + OrthoGrad + AdamW) of the same shape on a bounded batch."""
     from oracle import restate
@@ -209,7 +241,7 @@ def main():
             greedy["tokens_per_s"] = round(float(gt.item()), 1)
         else:
             greedy["tokens_per_s"] = greedy["tokens_per_s_per_gpu"]
-        extras = {"roofline": roof, "roofline_bf16": roof_bf16, "greedy": greedy}
+        extras = {"roofline": roof, "roofline_bf16": roof_bf16, "roofline_mfma": gemm_roofline(device), "greedy": greedy}
         if rank == 0 and world == 1:
             extras["cpu_baseline"] = cpu_baseline(c)
 
