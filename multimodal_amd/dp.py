@@ -22,6 +22,10 @@ class GradBuckets:
     the given order, so that one GEMM can produce their stacked gradient (the fused q/k/v projection)."""
 
     ALIGN = 64          # elements
+    GATHER_BELOW = 1 << 16
+    # Parameters smaller than this do not accumulate into their slot one elementwise launch each: zero() leaves their
+    # .grad unset, autograd then simply keeps the gradient tensor it was handed, and gather() moves all of a bucket's
+    # small gradients into their slots with one multi-tensor copy before the bucket is reduced / the optimizer runs.
 
     def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 128 << 20, comm_dtype=None, adjacent=()):
         self.params = [p for p in params if p.requires_grad]
@@ -51,10 +55,12 @@ class GradBuckets:
         flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
         off = 0
         for p in plist:
-            p.grad = flat[off: off + p.numel()].view_as(p)
+            p._mm_view = flat[off: off + p.numel()].view_as(p)
+            p.grad = p._mm_view
             p._mm_slot = (flat, off)
             off += -(-p.numel() // self.ALIGN) * self.ALIGN
-        self.buckets.append(dict(flat=flat, params=list(plist), pending=len(plist), work=None))
+        self.buckets.append(dict(flat=flat, params=list(plist), pending=len(plist), work=None,
+                                 small=[p for p in plist if p.numel() < self.GATHER_BELOW]))
 
     def zero(self):
         """Zero every bucket and mark the parameters fresh: a node that produces a whole weight gradient in one GEMM
@@ -63,10 +69,27 @@ class GradBuckets:
             b["flat"].zero_()
             for p in b["params"]:
                 p._mm_fresh = True
+                p.grad = p._mm_view
+            for p in b["small"]:
+                p.grad = None
+
+    def gather(self, b):
+        """Move the small gradients autograd left outside the bucket into their slots (one multi-tensor copy) and
+        point every .grad at its slot again."""
+        src, dst = [], []
+        for p in b["small"]:
+            g = p.grad
+            if g is not None and g is not p._mm_view:
+                dst.append(p._mm_view)
+                src.append(g.detach().reshape(p.shape).to(p._mm_view.dtype))
+            p.grad = p._mm_view
+        if src:
+            torch._foreach_copy_(dst, src)
 
 
 class DataParallel:
-    """Wraps a replicated module.  Usage per step:  dp.zero_grad(); loss.backward(); dp.finish(); optimizer.step()."""
+    """Wraps a replicated module.  Usage per step:  dp.zero_grad(); loss.backward(); dp.finish(); optimizer.step().
+    Gradients are complete (all in their bucket slots, averaged over ranks) only after finish()."""
 
     def __init__(self, module: torch.nn.Module, process_group=None, bucket_bytes: int = 128 << 20, overlap: bool = True):
         self.module = module
@@ -91,6 +114,7 @@ class DataParallel:
             dist.broadcast(t.data, src, group=self.pg)
 
     def _launch(self, b):
+        self.buckets.gather(b)
         b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def _hook(self, p):
@@ -109,6 +133,8 @@ class DataParallel:
         """Wait for every bucket's all-reduce and average.  Parameters that received no gradient this step still
         take part (their bucket slots are zero), so every rank issues the same collectives in the same order."""
         if self.world == 1:
+            for b in self.buckets.buckets:
+                self.buckets.gather(b)
             return
         for b in self.buckets.buckets:
             if b["work"] is None:

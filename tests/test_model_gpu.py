@@ -91,12 +91,13 @@ def test_backward_fp32_vs_reference_golden(golden_meta, name):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_bucket_direct_weight_grads_equal_autograd(golden_meta, dtype):
+def test_bucket_direct_weight_grads_equal_autograd(golden_meta, dtype, monkeypatch):
     """With dp.DataParallel the decoder node writes weight gradients straight into the (fresh) bucket slots, q/k/v
     stacked in one GEMM; the result must equal what autograd accumulates without buckets, a second backward must
     accumulate on top, and the optimizer step must invalidate the cached bf16 operands."""
-    from multimodal_amd.dp import DataParallel
+    from multimodal_amd.dp import DataParallel, GradBuckets
     from multimodal_amd.optim import OrthoGradAdamW
+    monkeypatch.setattr(GradBuckets, "GATHER_BELOW", 1024)     # this small model's 200x200 weights take the direct path
     case = golden_meta["cases"]["d100_sm"]
     ir, nmr, tgt = case_inputs(case)
     tg = tgt.to(DEV)
@@ -116,8 +117,10 @@ def test_bucket_direct_weight_grads_equal_autograd(golden_meta, dtype):
     dp.zero_grad()
     loss_of(m).backward()
     assert not lay.q.weight._mm_fresh and not lay.ffn_w1.weight._mm_fresh          # the direct path ran
+    assert lay.q.bias.grad is not lay.q.bias._mm_view                              # small gradients: gathered by finish()
+    dp.finish()
     for k, p in m.named_parameters():
-        assert torch.equal(p.grad, ref[k]), k
+        assert p.grad is p._mm_view and torch.equal(p.grad, ref[k]), k
     loss_of(m).backward()                                                           # no zero_grad: accumulates
     for k, p in m.named_parameters():
         assert rel_err(p.grad, 2 * ref[k]) < 1e-6, k
