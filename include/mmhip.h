@@ -177,7 +177,10 @@ int mm_cast_transpose(const float* in, void* out, int64_t R, int64_t C, int64_t 
  * descs[n_tensors]; the parameters are cut into chunks of chunk_elems elements: chunk_tensor[c], chunk_off[c];
  * tensor_chunk_start[n_tensors+1] (chunks of a tensor are consecutive).  g is overwritten with the projected
  * gradient (as the reference does), p/m/v are updated in place.  step counts from 1. */
-typedef struct { float* p; float* g; float* m; float* v; int64_t n; } mm_param_desc;
+typedef struct {
+    float* p; float* g; float* m; float* v; int64_t n;
+    void* w16;      /* optional bf16 copy of p (n elements) refreshed by the update, or NULL: the GEMM operand of the next step */
+} mm_param_desc;
 size_t mm_orthograd_adamw_workspace(int64_t n_tensors, int64_t n_chunks);
 int mm_orthograd_adamw(const mm_param_desc* descs, const int32_t* chunk_tensor, const int64_t* chunk_off,
                        const int32_t* tensor_chunk_start, int64_t n_tensors, int64_t n_chunks, int64_t chunk_elems,

@@ -161,7 +161,9 @@ __global__ __launch_bounds__(256) void og_adamw_k(const mm_param_desc* __restric
         const float v = b2 * d.v[i] + (1.f - b2) * g * g;
         d.m[i] = m; d.v[i] = v;
         const float denom = sqrtf(v) / bc2s + eps;
-        d.p[i] = w - step_size * (m / denom);
+        const float wn = w - step_size * (m / denom);
+        d.p[i] = wn;
+        if (d.w16) ((bf16*)d.w16)[i] = __float2bfloat16(wn);
     }
 }
 extern "C" size_t mm_orthograd_adamw_workspace(int64_t n_tensors, int64_t n_chunks) {

@@ -85,7 +85,7 @@ class ConvNeXtBlock(torch.autograd.Function):
         train = any(ctx.needs_input_grad)
         dt = x.dtype
         xn, mean, rstd = ops.dwconv7_ln_fwd(x, dw_w.detach(), dw_b.detach(), ln_w.detach(), ln_b.detach(), save_stats=train)
-        w1c, w2c = _w(w1, dt), _w(w2, dt)
+        w1c, w2c = cached_operand((w1,), dt), cached_operand((w2,), dt)
         h = torch.empty((M, 4 * Cc), dtype=dt, device=x.device) if train else None
         a = ops.gemm(xn.view(M, Cc), w1c, M, 4 * Cc, Cc, bias=b1.detach(), pre=h, act=ops.ACT_GELU)
         z = torch.empty((M, Cc), dtype=dt, device=x.device) if train else None
@@ -105,7 +105,7 @@ class ConvNeXtBlock(torch.autograd.Function):
         dout = dout.contiguous().view(M, Cc)
         gvec = gamma.detach() if gamma is not None else torch.ones(Cc, dtype=torch.float32, device=x.device)
         dz, dgamma, db2 = ops.layerscale_bwd(dout, z, gvec, dp_scale, Ln)
-        w1c, w2c = _w(w1, dt), _w(w2, dt)
+        w1c, w2c = cached_operand((w1,), dt), cached_operand((w2,), dt)
         dw2 = ops.gemm(dz, a, Cc, 4 * Cc, M, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32,
                        split_k=_split_k(Cc, 4 * Cc, M))
         dh = ops.gemm(dz, w2c, M, 4 * Cc, Cc, b_kmajor=True, mul=h, act=ops.ACT_GELU)
@@ -239,7 +239,40 @@ def cached_operand(params, dtype, transpose: bool = False) -> Tensor:
                 buf[off: off + p.shape[0]].copy_(p)
             off += p.shape[0]
     _operand_cache[key] = (stamp, buf, tuple(weakref.ref(p) for p in params))
+    if not transpose and dtype == torch.bfloat16 and all(p.dtype == torch.float32 for p in params):
+        off = 0
+        for p in params:                       # contiguous per-parameter row blocks: the optimizer can refresh them
+            _shadow_index[id(p)] = (key, off)
+            off += p.shape[0]
     return buf
+
+
+_shadow_index = {}
+
+
+def shadow_of(p: Tensor) -> Optional[Tensor]:
+    """The bf16 operand copy of parameter p inside the cache (a contiguous view of p's shape), or None."""
+    hit = _shadow_index.get(id(p))
+    if hit is None:
+        return None
+    key, off = hit
+    ent = _operand_cache.get(key)
+    if ent is None or not any(r() is p for r in ent[2]) or ent[1].device != p.device:
+        return None
+    return ent[1][off: off + p.shape[0]]
+
+
+def shadows_written(params) -> None:
+    """OrthoGradAdamW refreshed the copies of `params` while updating them: re-stamp the cache entries all of whose
+    parameters were refreshed, so the next forward takes the copies as current."""
+    done = set(id(p) for p in params)
+    for key in set(_shadow_index[i][0] for i in done if i in _shadow_index):
+        ent = _operand_cache.get(key)
+        if ent is None:
+            continue
+        ps = [r() for r in ent[2]]
+        if all(q is not None and id(q) in done for q in ps):
+            _operand_cache[key] = (tuple((q._version, q.data_ptr()) for q in ps), ent[1], ent[2])
 
 
 def _mm_f32(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:

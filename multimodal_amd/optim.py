@@ -10,13 +10,15 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import functional as FN
 from . import ops
 
 CHUNK = 1 << 16
 
 
 class ParamDesc(C.Structure):
-    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64),
+                ("w16", C.c_void_p)]
 
 
 class OrthoGradAdamW(torch.optim.Optimizer):
@@ -28,7 +30,11 @@ class OrthoGradAdamW(torch.optim.Optimizer):
         self._tables = {}
         self._step = 0
 
-    def _build(self, gi, plist):
+    @staticmethod
+    def _key(plist, shadows):
+        return tuple((p.data_ptr(), p.grad.data_ptr(), 0 if s is None else s.data_ptr()) for p, s in zip(plist, shadows))
+
+    def _build(self, gi, plist, shadows):
         dev = plist[0].device
         descs = (ParamDesc * len(plist))()
         ct, co, tcs = [], [], [0]
@@ -40,13 +46,14 @@ class OrthoGradAdamW(torch.optim.Optimizer):
             descs[t].p, descs[t].g = p.data_ptr(), p.grad.data_ptr()
             descs[t].m, descs[t].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             descs[t].n = p.numel()
+            descs[t].w16 = None if shadows[t] is None else shadows[t].data_ptr()
             nch = (p.numel() + CHUNK - 1) // CHUNK
             ct += [t] * nch
             co += [i * CHUNK for i in range(nch)]
             tcs.append(tcs[-1] + nch)
         raw = np.frombuffer(bytes(descs), dtype=np.uint8)
         tab = dict(
-            key=tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist),
+            key=self._key(plist, shadows),
             descs=torch.from_numpy(raw.copy()).to(dev),
             ct=torch.tensor(ct, dtype=torch.int32, device=dev), co=torch.tensor(co, dtype=torch.int64, device=dev),
             tcs=torch.tensor(tcs, dtype=torch.int32, device=dev), n_tensors=len(plist), n_chunks=len(ct))
@@ -67,10 +74,12 @@ class OrthoGradAdamW(torch.optim.Optimizer):
             for p in plist:
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
                     raise RuntimeError("OrthoGradAdamW: float32 contiguous GPU parameters and gradients only")
+            # bf16 GEMM-operand copies the model keeps of these parameters (functional.cached_operand): the update
+            # refreshes them in the same pass, so no cast kernels run in the next forward
+            shadows = [FN.shadow_of(p) for p in plist]
             tab = self._tables.get(gi)
-            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
-            if tab is None or tab["key"] != key:
-                tab = self._build(gi, plist)
+            if tab is None or tab["key"] != self._key(plist, shadows):
+                tab = self._build(gi, plist, shadows)
             nbytes = L.lib().mm_orthograd_adamw_workspace(tab["n_tensors"], tab["n_chunks"])
             ws = ops.workspace(nbytes, plist[0].device, "optim")
             b1, b2 = group["betas"]
@@ -80,4 +89,5 @@ class OrthoGradAdamW(torch.optim.Optimizer):
                                                int(group["ortho"]), L.ptr(ws), nbytes, L.cur_stream()), "mm_orthograd_adamw")
             # the kernel writes through raw pointers: tell autograd (and functional.cached_operand) the values moved
             torch.autograd.graph.increment_version(plist)
+            FN.shadows_written([p for p, s in zip(plist, shadows) if s is not None])
         return loss
