@@ -119,6 +119,10 @@ if __name__ == "__main__":
         for sh in a.shapes.split(";"):
             M, N, K = (int(v) for v in sh.split(","))
             res.append(bench_gemm(M, N, K, torch.bfloat16)); print(json.dumps(res[-1]), flush=True)
-    if "attn" in a.what:
+    if "attnx" in a.what:
+        for sh in a.shapes.split(";"):
+            B, H, d, S, P = (int(v) for v in sh.split(","))
+            res.append(bench_attn(B, H, d, S, P, torch.bfloat16, True)); print(json.dumps(res[-1]), flush=True)
+    if "attn" in a.what.split(","):
         for (B, H, d, S, P, sm) in [(32, 16, 100, 315, 221, True), (32, 8, 128, 238, 159, False), (32, 4, 192, 315, 221, True), (32, 4, 512, 315, 221, True)]:
             res.append(bench_attn(B, H, d, S, P, torch.bfloat16, sm)); print(json.dumps(res[-1]), flush=True)

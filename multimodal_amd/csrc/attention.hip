@@ -97,6 +97,8 @@ __device__ __forceinline__ bool attn_allowed(int qi, int kj, int P, int S) {
     return kj < S && (kj <= qi || (qi < P && kj < P));
 }
 __device__ __forceinline__ float stable_s_f(float x) { return x < 0.f ? 1.0f / ((1.0f - x) + 1e-9f) : x + 1.0f; }
+// bf16 kernels: hardware reciprocal (1 ulp) instead of the IEEE division sequence -- far below bf16 rounding
+__device__ __forceinline__ float stable_s_fast(float x) { return x < 0.f ? __builtin_amdgcn_rcpf((1.0f - x) + 1e-9f) : x + 1.0f; }
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -271,13 +273,29 @@ struct TileRegs { static constexpr int IT = NROWS * (DP / 4) / 256; uint2 v[IT];
 template <int DP, int NROWS>
 __device__ __forceinline__ void tile_load(TileRegs<DP, NROWS>& r, const bf16* __restrict__ g, long ld, int row0, int S, int d) {
     constexpr int V4 = DP / 4;
+    if constexpr (256 % V4 == 0) {
+        // a thread keeps its column and walks rows rr0, rr0+RS, ...: every load is (wave-uniform row base) + (one fixed
+        // 32-bit per-lane offset), i.e. the scalar-base addressing form with no per-load vector address arithmetic
+        constexpr int RS = 256 / V4;
+        const int rr0 = threadIdx.x / V4, c = (threadIdx.x % V4) * 4;
+        const unsigned voff = (unsigned)(rr0 * ld + c) * 2u;
+        const char* base = reinterpret_cast<const char*>(g) + (long)row0 * ld * 2;
+        const bool col_ok = c < d;
 #pragma unroll
-    for (int j = 0; j < TileRegs<DP, NROWS>::IT; j++) {
-        const int idx = threadIdx.x + j * 256;
-        const int rr = idx / V4, c = (idx % V4) * 4;
-        const int row = row0 + rr;
-        if (row < S && c < d) r.v[j] = *reinterpret_cast<const uint2*>(g + (long)row * ld + c);
-        else r.v[j] = make_uint2(0u, 0u);
+        for (int j = 0; j < TileRegs<DP, NROWS>::IT; j++) {
+            const int row = row0 + rr0 + j * RS;
+            if (col_ok && row < S) r.v[j] = *reinterpret_cast<const uint2*>(base + (long)(j * RS) * ld * 2 + voff);
+            else r.v[j] = make_uint2(0u, 0u);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TileRegs<DP, NROWS>::IT; j++) {
+            const int idx = threadIdx.x + j * 256;
+            const int rr = idx / V4, c = (idx % V4) * 4;
+            const int row = row0 + rr;
+            if (row < S && c < d) r.v[j] = *reinterpret_cast<const uint2*>(g + (long)row * ld + c);
+            else r.v[j] = make_uint2(0u, 0u);
+        }
     }
 }
 template <int DP, int NROWS>
@@ -364,16 +382,22 @@ __global__ __launch_bounds__(256) void prefix_attn_fwd2_k(const AttnP p) {
             }
             float pv[4 * NT16];
             float tmax = -INFINITY;
+            // interior tiles (every key visible to every query of the wave) skip the per-element mask arithmetic
+            const bool full = k0 + KT <= p.S && ((k0 + KT - 1 <= qw0) || (qw0 + 15 < p.P && k0 + KT <= p.P));
+            auto fill = [&](auto fc) {
+                constexpr bool FULL = decltype(fc)::value;
 #pragma unroll
-            for (int t = 0; t < NT16; t++)
+                for (int t = 0; t < NT16; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int kj = k0 + 16 * t + 4 * fg + r;
-                    const float x = sacc[t][r] * p.scale;
-                    const bool ok = attn_allowed(qi, kj, p.P, p.S);
-                    if (STABLE) pv[4 * t + r] = ok ? stable_s_f(x) : 0.f;
-                    else { pv[4 * t + r] = ok ? x : -INFINITY; tmax = fmaxf(tmax, pv[4 * t + r]); }
-                }
+                    for (int r = 0; r < 4; r++) {
+                        const int kj = k0 + 16 * t + 4 * fg + r;
+                        const float x = sacc[t][r] * p.scale;
+                        const bool ok = FULL || attn_allowed(qi, kj, p.P, p.S);
+                        if (STABLE) pv[4 * t + r] = ok ? stable_s_fast(x) : 0.f;
+                        else { pv[4 * t + r] = ok ? x : -INFINITY; tmax = fmaxf(tmax, pv[4 * t + r]); }
+                    }
+            };
+            if (full) fill(std::true_type{}); else fill(std::false_type{});
             if (!STABLE) {
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
@@ -1150,23 +1174,28 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dq5_k(const AttnP p) {
                     da[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[ks], da[t], 0, 0, 0);
                 }
             }
+            const bool full = k0 + KT <= p.S && qw0 + 15 < p.S && ((k0 + KT - 1 <= qw0) || (qw0 + 15 < p.P && k0 + KT <= p.P));
 #pragma unroll
             for (int kk = 0; kk < KT / 32; kk++) {
                 bf16x8_t dsf;
+                auto fill = [&](auto fc) {
+                    constexpr bool FULL = decltype(fc)::value;
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++)
+                    for (int tt = 0; tt < 2; tt++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int t = 2 * kk + tt;
-                        const int kj = k0 + 16 * t + 4 * fg + r;
-                        const float x = sa[t][r] * p.scale;
-                        float ds = 0.f;
-                        if (qok && attn_allowed(qi, kj, p.P, p.S)) {
-                            if (STABLE) { const float sx = stable_s_f(x); ds = (da[t][r] - dlt) * invL * (x < 0.f ? sx * sx : 1.f); }
-                            else { const float pr = __expf(x - lse); ds = pr * (da[t][r] - dlt); }
+                        for (int r = 0; r < 4; r++) {
+                            const int t = 2 * kk + tt;
+                            const int kj = k0 + 16 * t + 4 * fg + r;
+                            const float x = sa[t][r] * p.scale;
+                            float ds = 0.f;
+                            if (FULL || (qok && attn_allowed(qi, kj, p.P, p.S))) {
+                                if (STABLE) { const float sx = stable_s_fast(x); ds = (da[t][r] - dlt) * invL * (x < 0.f ? sx * sx : 1.f); }
+                                else { const float pr = __expf(x - lse); ds = pr * (da[t][r] - dlt); }
+                            }
+                            dsf[4 * tt + r] = (short)f2bf(ds);
                         }
-                        dsf[4 * tt + r] = (short)f2bf(ds);
-                    }
+                };
+                if (full) fill(std::true_type{}); else fill(std::false_type{});
                 if (k0 + 32 * kk < kend_w) {             // wave-uniform: later keys are masked for every query here
 #pragma unroll
                     for (int n = 0; n < NDV; n++) {
@@ -1231,6 +1260,7 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dkv5_k(const AttnP p) {
     if (tid < QT) {
         const int qi = qstart_blk + tid;
         st_l = qi < p.S ? p.lse[statbase + qi] : 1.f; st_d = qi < p.S ? p.delta[statbase + qi] : 0.f;
+        if (STABLE) st_l = 1.0f / fmaxf(st_l, 1e-9f);
     }
 
     f32x4_t dka[NDV], dva[NDV];
@@ -1250,6 +1280,7 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dkv5_k(const AttnP p) {
             if (tid < QT) {
                 const int qi = q0 + QT + tid;
                 st_l = qi < p.S ? p.lse[statbase + qi] : 1.f; st_d = qi < p.S ? p.delta[statbase + qi] : 0.f;
+                if (STABLE) st_l = 1.0f / fmaxf(st_l, 1e-9f);
             }
         }
         if (wave_live && q0 + QT > qstart_w) {
@@ -1266,27 +1297,34 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dkv5_k(const AttnP p) {
                     da[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf[ks], da[t], 0, 0, 0);
                 }
             }
+            const bool full = kw0 + 15 < p.S && q0 + QT <= p.S && ((kw0 + 15 <= q0) || (q0 + QT <= p.P && kw0 + 15 < p.P));
 #pragma unroll
             for (int kk = 0; kk < QT / 32; kk++) {
                 bf16x8_t pf, dsf;
+                auto fill = [&](auto fc) {
+                    constexpr bool FULL = decltype(fc)::value;
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
+                    for (int tt = 0; tt < 2; tt++) {
                         const int t = 2 * kk + tt;
-                        const int ql = 16 * t + 4 * fg + r;
-                        const int qi = q0 + ql;
-                        const float x = sa[t][r] * p.scale;
-                        float pr = 0.f, ds = 0.f;
-                        if (qi < p.S && attn_allowed(qi, kj, p.P, p.S)) {
-                            const float lse = lstat[ql], dlt = lstat[QT + ql];
-                            if (STABLE) {
-                                const float sx = stable_s_f(x), invL = 1.0f / fmaxf(lse, 1e-9f);
-                                pr = sx * invL; ds = (da[t][r] - dlt) * invL * (x < 0.f ? sx * sx : 1.f);
-                            } else { pr = __expf(x - lse); ds = pr * (da[t][r] - dlt); }
+                        // row statistics of queries 16t+4fg .. +3: lstat holds 1/L (stablemax) or lse (softmax), then delta
+                        const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(&lstat[16 * t + 4 * fg]);
+                        const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(&lstat[QT + 16 * t + 4 * fg]);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int qi = q0 + 16 * t + 4 * fg + r;
+                            const float x = sa[t][r] * p.scale;
+                            float pr = 0.f, ds = 0.f;
+                            if (FULL || (qi < p.S && attn_allowed(qi, kj, p.P, p.S))) {
+                                if (STABLE) {
+                                    const float sx = stable_s_fast(x), invL = l4[r];
+                                    pr = sx * invL; ds = (da[t][r] - d4[r]) * invL * (x < 0.f ? sx * sx : 1.f);
+                                } else { pr = __expf(x - l4[r]); ds = pr * (da[t][r] - d4[r]); }
+                            }
+                            pf[4 * tt + r] = (short)f2bf(pr); dsf[4 * tt + r] = (short)f2bf(ds);
                         }
-                        pf[4 * tt + r] = (short)f2bf(pr); dsf[4 * tt + r] = (short)f2bf(ds);
                     }
+                };
+                if (full) fill(std::true_type{}); else fill(std::false_type{});
                 if (q0 + 32 * kk + 32 > qstart_w) {      // wave-uniform: earlier queries see none of this wave's keys
 #pragma unroll
                     for (int n = 0; n < NDV; n++) {
