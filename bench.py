@@ -123,7 +123,7 @@ def greedy_bench(device, world, rank):
             "config": "local_config_nocat", "dtype": "bf16", "kv_cache": True, "seconds": round(dt, 4)}
 
 
-def cpu_baseline(c, sample_b=16):
+def cpu_baseline(c, sample_b=32):
     """The CPU oracle (oracle/restate.py, pinned against the reference) timed on the host cores: one train step
     (forward + CE + backward + OrthoGrad + AdamW) of the same shape on a bounded batch."""
     from oracle import restate

@@ -16,6 +16,8 @@
 #include "common.h"
 #include "gemm_epi.h"
 #include <stdlib.h>
+#include <utility>
+#include <type_traits>
 
 namespace {
 constexpr int BK = 64;
@@ -39,14 +41,15 @@ template <> struct Raw8<float> {
     }
 };
 
-template <int TM, int TN> struct BigTile {
-    static constexpr int BM = 32 * TM, BN = 64 * TN;
+template <int TM, int TN, int WN> struct BigTile {
+    static constexpr int NW = 2 * WN;                                  // waves: 2 along M x WN along N
+    static constexpr int BM = 32 * TM, BN = 16 * TN * WN;
     static constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
     static constexpr int EPI_ROW = TN * 64 + 16;                       // padded f32 row of a wave's window (bytes)
     static constexpr int EPI_WAVE = 16 * EPI_ROW;                      // 16 rows a pass; 8 windows fit in ONE stage
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
     static constexpr int PIECES = (BM + BN) / 8;                       // 1 KiB DMA pieces (8 rows) per stage
-    static constexpr int PPW = (PIECES + 7) / 8;                       // pieces per wave (the last may be absent)
+    static constexpr int PPW = (PIECES + NW - 1) / NW;                 // pieces per wave (the last may be absent)
 };
 
 // ---- epilogue through LDS: a wave transposes its TM x TN accumulator tiles 16 rows a pass through a private window
@@ -66,7 +69,7 @@ __device__ __forceinline__ void big_epilogue(const GemmP& p, f32x4_t (&acc)[TM][
     };
     if (fast) {
         // lane -> fixed column group (so the bias is read once), rows r0 + RPI*it of the pass
-        constexpr int CG = TN == 4 ? 8 : 16, RPI = 64 / CG, NIT2 = 16 / RPI;
+        constexpr int CG = LPR <= 8 ? 8 : (LPR <= 16 ? 16 : 32), RPI = 64 / CG, NIT2 = 16 / RPI;
         const TO* extra = (const TO*)(p.mul ? p.mul : p.res);
         const int c8 = lane % CG, r0 = lane / CG;
         const long n = nw + c8 * 8;
@@ -148,13 +151,13 @@ __device__ __forceinline__ void big_epilogue(const GemmP& p, f32x4_t (&acc)[TM][
     }
 }
 
-template <typename TO, int TM, int TN>
-__global__ __launch_bounds__(512, 1) void gemm_big_k(const GemmP p) {
-    typedef BigTile<TM, TN> G;
+template <typename TO, int TM, int TN, int WN>
+__global__ __launch_bounds__(128 * WN, 1) void gemm_big_k(const GemmP p) {
+    typedef BigTile<TM, TN, WN> G;
     constexpr int BM = G::BM, BN = G::BN;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / WN, wc = wave % WN;
     const int nk = p.K / BK;
     const int nwg = p.tiles_m * p.tiles_n;
 
@@ -165,10 +168,10 @@ __global__ __launch_bounds__(512, 1) void gemm_big_k(const GemmP p) {
     for (int ks = 0; ks < 2; ks++) {
         const int slot = ((ks * 4 + fg) ^ (fr >> 1)) << 4;
         offA[ks] = (wr * (BM / 2) + fr) * 128 + slot;
-        offB[ks] = (BM + wc * (BN / 4) + fr) * 128 + slot;
+        offB[ks] = (BM + wc * (BN / WN) + fr) * 128 + slot;
     }
 
-    // ---- staging: piece q = wave + 8*i covers rows 8q .. 8q+7 of the stacked [A rows ; B rows] image
+    // ---- staging: piece q = wave + NW*i covers rows 8q .. 8q+7 of the stacked [A rows ; B rows] image
     const bf16* src[G::PPW];
     auto tile_origin = [&](int id, long& m0, long& n0) {              // XCD-aware bijective remap, N fastest
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_k(const GemmP p) {
     auto set_sources = [&](long m0, long n0) {
 #pragma unroll
         for (int i = 0; i < G::PPW; i++) {
-            const int q = wave + 8 * i;
+            const int q = wave + G::NW * i;
             const int row = q * 8 + (lane >> 3);                       // stacked row; the swizzle uses the operand-local row
             const bool isA = row < BM;
             const int lrow = isA ? row : row - BM;
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_k(const GemmP p) {
         unsigned char* base = smem + buf * G::STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < G::PPW; i++) {
-            const int q = wave + 8 * i;
+            const int q = wave + G::NW * i;
             if (q < G::PIECES)                                         // wave-uniform
                 __builtin_amdgcn_global_load_lds((glb_vp)(src[i] + (long)kt * BK), (lds_vp)(base + q * 1024), 16, 0, 0);
         }
@@ -234,21 +237,21 @@ __global__ __launch_bounds__(512, 1) void gemm_big_k(const GemmP p) {
             }
         }
         __syncthreads();                                   // every wave is done with both operand stages
-        big_epilogue<TO, TM, TN, G::EPI_ROW>(p, acc, smem + G::STAGE_BYTES + wave * G::EPI_WAVE, m0 + wr * (BM / 2), n0 + wc * (BN / 4), lane);
+        big_epilogue<TO, TM, TN, G::EPI_ROW>(p, acc, smem + G::STAGE_BYTES + wave * G::EPI_WAVE, m0 + wr * (BM / 2), n0 + wc * (BN / WN), lane);
     }
 }
 
-template <typename TO, int TM, int TN>
+template <typename TO, int TM, int TN, int WN>
 int launch_big(const GemmP& p, hipStream_t st) {
-    typedef BigTile<TM, TN> G;
+    typedef BigTile<TM, TN, WN> G;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_big_k<TO, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_big_k<TO, TM, TN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e != hipSuccess) MM_FAIL(MM_ERR_LAUNCH, "gemm_big: cannot raise dynamic LDS to %d bytes: %s", G::LDS_BYTES, hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((gemm_big_k<TO, TM, TN>), dim3((unsigned)tiles), dim3(512), G::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_big_k<TO, TM, TN, WN>), dim3((unsigned)tiles), dim3(128 * WN), G::LDS_BYTES, st, p);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
@@ -284,7 +287,7 @@ int gemm_big_launch(GemmP& p, int out_dtype, hipStream_t st) {
         for (int i = 1; i < 4; i++) if (shape_cost(p, kShapes[i]) < shape_cost(p, kShapes[best]) * 0.97) best = i;
     const Shape s = kShapes[best];
     p.tiles_m = (int)cdiv(p.M, 32 * s.tm); p.tiles_n = (int)cdiv(p.N, 64 * s.tn);
-#define GO_(TM_, TN_) return out_dtype == MM_BF16 ? launch_big<bf16, TM_, TN_>(p, st) : launch_big<float, TM_, TN_>(p, st)
+#define GO_(TM_, TN_) return out_dtype == MM_BF16 ? launch_big<bf16, TM_, TN_, 4>(p, st) : launch_big<float, TM_, TN_, 4>(p, st)
     switch (best) {
         case 0: GO_(8, 4);
         case 1: GO_(7, 4);
