@@ -1,6 +1,2 @@
-SH="10080,6400,1600;10080,1600,6400;4096,4096,4096;8192,8192,8192"
-echo 4wave-pipe; MM_GEMM_BIG_4WAVE=1 timeout -k 10 300 python -u -m pytest tests/test_kernels_gpu.py -x -q --timeout 120 --timeout-method thread -k "gemm_large" 2>&1 | tail -1 || exit 1
-MM_GEMM_BIG_4WAVE=1 timeout -k 10 200 python benchmarks/kernel_bench.py --what gemmx --shapes "$SH" 2>&1 | grep bfloat16 | cut -c 18-60,100-200 || exit 1
-echo 8wave-pipe; MM_GEMM_BIG_PIPE=1 timeout -k 10 300 python -u -m pytest tests/test_kernels_gpu.py -x -q --timeout 120 --timeout-method thread -k "gemm_large" 2>&1 | tail -1 || exit 1
-MM_GEMM_BIG_PIPE=1 timeout -k 10 200 python benchmarks/kernel_bench.py --what gemmx --shapes "$SH" 2>&1 | grep bfloat16 | cut -c 18-60,100-200 || exit 1
-echo 8wave; timeout -k 10 200 python benchmarks/kernel_bench.py --what gemmx --shapes "$SH" 2>&1 | grep bfloat16 | cut -c 18-60,100-200
+SH="32,16,100,315,221;32,8,128,238,159"
+for v in base a b c; do echo $v; L=""; [ $v != base ] && L=$PWD/multimodal_amd/lib/libmmhip_$v.so; MM_LIB=$L timeout -k 10 200 python benchmarks/kernel_bench.py --what attnx --shapes "$SH" 2>&1 | grep prefix | cut -c 24-60,130-300 || exit 1; done
