@@ -22,10 +22,10 @@ class GradBuckets:
     the given order, so that one GEMM can produce their stacked gradient (the fused q/k/v projection)."""
 
     ALIGN = 64          # elements
-    GATHER_BELOW = 1 << 16
-    # Parameters smaller than this do not accumulate into their slot one elementwise launch each: zero() leaves their
-    # .grad unset, autograd then simply keeps the gradient tensor it was handed, and gather() moves all of a bucket's
-    # small gradients into their slots with one multi-tensor copy before the bucket is reduced / the optimizer runs.
+    # zero() does not touch the buffers: it unsets every .grad.  Autograd then keeps the gradient tensor it is handed
+    # (no accumulate launch), nodes that produce a whole weight gradient in one GEMM write the slot directly
+    # (functional._weight_grad), and gather() completes a bucket before it is reduced / the optimizer runs: one
+    # multi-tensor copy for the gradients left outside, one multi-tensor zero for the slots nobody wrote.
 
     def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 128 << 20, comm_dtype=None, adjacent=()):
         self.params = [p for p in params if p.requires_grad]
@@ -59,32 +59,30 @@ class GradBuckets:
             p.grad = p._mm_view
             p._mm_slot = (flat, off)
             off += -(-p.numel() // self.ALIGN) * self.ALIGN
-        self.buckets.append(dict(flat=flat, params=list(plist), pending=len(plist), work=None,
-                                 small=[p for p in plist if p.numel() < self.GATHER_BELOW]))
+        self.buckets.append(dict(flat=flat, params=list(plist), pending=len(plist), work=None))
 
     def zero(self):
-        """Zero every bucket and mark the parameters fresh: a node that produces a whole weight gradient in one GEMM
-        (functional._weight_grad) may then write its bucket slot directly instead of accumulating into it."""
         for b in self.buckets:
-            b["flat"].zero_()
             for p in b["params"]:
                 p._mm_fresh = True
-                p.grad = p._mm_view
-            for p in b["small"]:
                 p.grad = None
 
     def gather(self, b):
-        """Move the small gradients autograd left outside the bucket into their slots (one multi-tensor copy) and
-        point every .grad at its slot again."""
-        src, dst = [], []
-        for p in b["small"]:
+        """Complete a bucket: copy in the gradients autograd left outside it, zero the slots that received nothing,
+        and point every .grad at its slot."""
+        src, dst, zero = [], [], []
+        for p in b["params"]:
             g = p.grad
-            if g is not None and g is not p._mm_view:
+            if g is None:
+                zero.append(p._mm_view)
+            elif g is not p._mm_view:
                 dst.append(p._mm_view)
                 src.append(g.detach().reshape(p.shape).to(p._mm_view.dtype))
             p.grad = p._mm_view
         if src:
             torch._foreach_copy_(dst, src)
+        if zero:
+            torch._foreach_zero_(zero)
 
 
 class DataParallel:

@@ -294,13 +294,13 @@ def _linear_res(x2: Tensor, w: Tensor, b: Tensor, res: Tensor) -> Tensor:
 
 
 def _weight_grad(p: Tensor, dy2: Tensor, x2: Tensor) -> Optional[Tensor]:
-    """dW = dy2^T @ x2 (float32).  When the data-parallel buckets have just zeroed p.grad (dp.GradBuckets marks the
-    parameter fresh) the GEMM writes the bucket slot directly and the bucket is told the gradient is ready; the node
-    then returns None for this parameter.  Otherwise the gradient goes back to autograd to be accumulated."""
-    g = p.grad
-    if g is not None and getattr(p, "_mm_fresh", False) and g.dtype == torch.float32 and g.is_contiguous() \
-            and g.shape == p.shape:
+    """dW = dy2^T @ x2 (float32).  When dp.GradBuckets.zero() has marked the parameter fresh and nothing has been
+    accumulated yet, the GEMM writes the parameter's bucket slot directly, .grad is pointed at it and the bucket is told
+    the gradient is ready; the node then returns None for this parameter.  Otherwise the gradient goes back to autograd."""
+    g = getattr(p, "_mm_view", None)
+    if g is not None and getattr(p, "_mm_fresh", False) and p.grad is None and g.dtype == torch.float32 and g.shape == p.shape:
         _mm_f32(dy2.t(), x2, out=g)
+        p.grad = g
         p._mm_fresh = False
         ready = getattr(p, "_mm_ready", None)
         if ready is not None:
@@ -314,13 +314,14 @@ def _stacked_weight_grads(params, dy2: Tensor, x2: Tensor):
     when dp.GradBuckets laid them out that way and all are fresh; else one GEMM each."""
     slots = [getattr(p, "_mm_slot", None) for p in params]
     n = params[0].numel()
-    if all(s is not None for s in slots) and all(getattr(p, "_mm_fresh", False) and p.grad is not None for p in params) \
+    if all(s is not None for s in slots) and all(getattr(p, "_mm_fresh", False) and p.grad is None for p in params) \
             and all(s[0] is slots[0][0] and s[1] == slots[0][1] + i * n and p.numel() == n
                     for i, (s, p) in enumerate(zip(slots, params))):
         flat, off = slots[0]
         out = flat[off: off + len(params) * n].view(len(params) * params[0].shape[0], params[0].shape[1])
         _mm_f32(dy2.t(), x2, out=out)
         for p in params:
+            p.grad = p._mm_view
             p._mm_fresh = False
             ready = getattr(p, "_mm_ready", None)
             if ready is not None:
