@@ -123,6 +123,68 @@ def greedy_bench(device, world, rank):
             "config": "local_config_nocat", "dtype": "bf16", "kv_cache": True, "seconds": round(dt, 4)}
 
 
+def train_leg(c, device, batch, dtype, steps, warmup, rank=0):
+    """Extra single-rank measurement of the same train step at another per-GPU batch / compute dtype (SURVEY 8d:
+    report the config batch and a saturating batch, bf16 and fp32)."""
+    import multimodal_amd as mm
+    from multimodal_amd.dp import DataParallel
+    from multimodal_amd.optim import OrthoGradAdamW
+    with mm.compute_dtype(dtype):
+        model = build_model(c, device).train()
+        dp = DataParallel(model)
+        opt = OrthoGradAdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, ortho=True,
+                             ortho_eps=1e-8, rescale=True)
+        ir, nmr, tgt = synth_batch(c, batch, device, 99 + rank)
+        crit = torch.nn.CrossEntropyLoss(ignore_index=0)
+
+        def step():
+            dp.zero_grad()
+            logits = model(nmr, ir, tgt[:, :-1], None)
+            crit(logits.reshape(-1, logits.size(-1)), tgt[:, 1:].reshape(-1)).backward()
+            dp.finish()
+            opt.step()
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    del model, dp, opt
+    torch.cuda.empty_cache()
+    return {"spectra_per_s_per_gpu": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 2), "per_gpu_batch": batch,
+            "dtype": str(dtype).replace("torch.", ""), "steps": steps}
+
+
+def greedy_nocache(device, B=128):
+    """The reference's decode loop (train_autoregressive.py:97-101: the whole decoder is re-run on the growing sequence
+    every step) on the same device and kernels, beside the KV-cached generate, same batch: the speed-up of row K4."""
+    import multimodal_amd as mm
+    c = CONFIGS["local_config_nocat"]
+    m = build_model(c, device).eval()
+    ir, nmr, _ = synth_batch(c, B, device, 777)
+    steps = c["max_seq"]
+    with mm.compute_dtype(torch.bfloat16), torch.no_grad():
+        m.generate(nmr[:8], ir[:8], max_len=4, early_stop=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.generate(nmr, ir, max_len=steps, early_stop=False)
+        torch.cuda.synchronize()
+        t_cache = time.perf_counter() - t0
+        mem = m.encoder(None, ir, None)
+        cur = torch.full((B, 1), 12, dtype=torch.long, device=device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            logits = m.decoder(cur, mem, nmr)
+            cur = torch.cat([cur, logits[:, -1].argmax(-1, keepdim=True)], 1)
+        torch.cuda.synchronize()
+        t_nocache = time.perf_counter() - t0
+    return {"batch": B, "steps": steps, "kv_cache_tokens_per_s": round(B * steps / t_cache, 1),
+            "recompute_tokens_per_s": round(B * steps / t_nocache, 1), "speedup": round(t_nocache / t_cache, 2)}
+
+
 def cpu_baseline(c, sample_b=32):
     """The CPU oracle (oracle/restate.py, pinned against the reference) timed on the host cores: one train step
     (forward + CE + backward + OrthoGrad + AdamW) of the same shape on a bounded batch."""
@@ -242,6 +304,11 @@ def main():
         else:
             greedy["tokens_per_s"] = greedy["tokens_per_s_per_gpu"]
         extras = {"roofline": roof, "roofline_bf16": roof_bf16, "roofline_mfma": gemm_roofline(device), "greedy": greedy}
+        extras["roofline"]["config_batch_latency_us"] = k1_roofline(device, torch.float32, B=32, iters=50)["launch_us"]
+        if world == 1:
+            extras["greedy_vs_recompute"] = greedy_nocache(device)
+            extras["train_batch256_bf16"] = train_leg(c, device, 256, torch.bfloat16, steps=4, warmup=2)
+            extras["train_batch32_fp32"] = train_leg(c, device, 32, torch.float32, steps=5, warmup=2)
         if rank == 0 and world == 1:
             extras["cpu_baseline"] = cpu_baseline(c)
 
