@@ -15,6 +15,8 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from . import functional as FN
+
 
 class GradBuckets:
     """p.grad become views into a few flat float buffers.  Every slot starts on a 256-byte boundary (GEMMs write
@@ -112,6 +114,7 @@ class DataParallel:
             dist.broadcast(t.data, src, group=self.pg)
 
     def _launch(self, b):
+        FN.join_side_stream()                 # parameter-gradient GEMMs a node may have put on its side stream
         self.buckets.gather(b)
         b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
@@ -131,6 +134,7 @@ class DataParallel:
         """Wait for every bucket's all-reduce and average.  Parameters that received no gradient this step still
         take part (their bucket slots are zero), so every rank issues the same collectives in the same order."""
         if self.world == 1:
+            FN.join_side_stream()
             for b in self.buckets.buckets:
                 self.buckets.gather(b)
             return

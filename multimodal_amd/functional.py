@@ -53,6 +53,32 @@ def _split_k(M: int, N: int, K: int) -> int:
     return int(max(1, min(32, 256 // tiles, K // 512)))
 
 
+# Weight / bias gradients are off the critical dX chain.  For the layers whose backward runs LAST (the first decoder
+# layers) they can be issued on a side stream: they then overlap the encoder's backward, which consists of many small,
+# latency-bound launches that leave most of the chip idle.  The autograd engine joins the side stream at the end of the
+# backward pass (queue_callback), and dp / the optimizer join it before they touch gradients.
+_side_streams = {}
+_ENC_SIDE = __import__("os").environ.get("MM_ENC_SIDE", "1") != "0"     # A/B switch
+_join_queued = False
+
+
+def side_stream(device) -> torch.cuda.Stream:
+    s = _side_streams.get(device)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _side_streams[device] = s
+    return s
+
+
+def join_side_stream() -> None:
+    """Make the current stream wait for every side-stream gradient launch issued so far."""
+    global _join_queued
+    _join_queued = False
+    for dev, s in _side_streams.items():
+        torch.cuda.current_stream(dev).wait_stream(s)
+
+
+
 # --------------------------------------------------------------------------------------------------
 class StemLN(torch.autograd.Function):
     """Conv1d(1,C0,k4,s4) + LayerNorm, [B,Lin] f32 -> [B,Lo,C0] (reference models/convnext.py:67-72)."""
@@ -106,12 +132,25 @@ class ConvNeXtBlock(torch.autograd.Function):
         gvec = gamma.detach() if gamma is not None else torch.ones(Cc, dtype=torch.float32, device=x.device)
         dz, dgamma, db2 = ops.layerscale_bwd(dout, z, gvec, dp_scale, Ln)
         w1c, w2c = cached_operand((w1,), dt), cached_operand((w2,), dt)
-        dw2 = ops.gemm(dz, a, Cc, 4 * Cc, M, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32,
-                       split_k=_split_k(Cc, 4 * Cc, M))
         dh = ops.gemm(dz, w2c, M, 4 * Cc, Cc, b_kmajor=True, mul=h, act=ops.ACT_GELU)
-        db1 = ops.colsum(dh, M, 4 * Cc)
-        dw1 = ops.gemm(dh, xn.view(M, Cc), 4 * Cc, Cc, M, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32,
-                       split_k=_split_k(4 * Cc, Cc, M))
+        # weight / bias gradients on the side stream (see DecoderLayer): the dX chain below does not wait for them
+        global _join_queued
+        main = torch.cuda.current_stream(x.device)
+        side = side_stream(x.device) if _ENC_SIDE else main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            dw2 = ops.gemm(dz, a, Cc, 4 * Cc, M, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32,
+                           split_k=_split_k(Cc, 4 * Cc, M), ws_tag="gemm_side")
+            db1 = ops.colsum(dh, M, 4 * Cc, "side")
+            dw1 = ops.gemm(dh, xn.view(M, Cc), 4 * Cc, Cc, M, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32,
+                           split_k=_split_k(4 * Cc, Cc, M), ws_tag="gemm_side")
+        for t in (dz, dh):
+            t.record_stream(side)
+        for t in (dw2, db1, dw1):
+            t.record_stream(main)
+        if not _join_queued:
+            _join_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
         dxn = ops.gemm(dh, w1c, M, Cc, 4 * Cc, b_kmajor=True)
         dx, ddw, ddb, dlw, dlb = ops.dwconv7_ln_bwd(x, dxn.view(B, Ln, Cc), dout.view(B, Ln, Cc), dw_w.detach(),
                                                     dw_b.detach(), ln_w.detach(), mean, rstd)
@@ -340,7 +379,7 @@ class DecoderLayer(torch.autograd.Function):
     the LayerNorm backward kernels; weight gradients are produced in float32."""
 
     @staticmethod
-    def forward(ctx, x, cos_t, sin_t, H, rot, prompt_len, stablemax, ln1w, ln1b, qw, qb, kw, kb, vw, vb, ow, ob,
+    def forward(ctx, x, cos_t, sin_t, H, rot, prompt_len, stablemax, defer_dw, ln1w, ln1b, qw, qb, kw, kb, vw, vb, ow, ob,
                 ln2w, ln2b, w1, b1, w2, b2):
         B, S, D = x.shape
         M = B * S
@@ -361,43 +400,65 @@ class DecoderLayer(torch.autograd.Function):
         if train:
             ctx.save_for_backward(x, mean1, rstd1, xa, qkv, o, lse, x1, mean2, rstd2, xf, h, a, cos_t, sin_t,
                                   ln1w, qw, kw, vw, ow, ln2w, w1, w2)
-            ctx.cfg = (H, rot, prompt_len, stablemax)
+            ctx.cfg = (H, rot, prompt_len, stablemax, bool(defer_dw))
         return out.view(B, S, D)
 
     @staticmethod
     def backward(ctx, dout):
         (x, mean1, rstd1, xa, qkv, o, lse, x1, mean2, rstd2, xf, h, a, cos_t, sin_t,
          ln1w, qw, kw, vw, ow, ln2w, w1, w2) = ctx.saved_tensors
-        H, rot, prompt_len, stablemax = ctx.cfg
+        H, rot, prompt_len, stablemax, defer_dw = ctx.cfg
         B, S, D = x.shape
         M = B * S
         dt = x.dtype
         F4 = h.shape[1]
         dout = dout.contiguous().view(M, D)
-        # ---- MLP
-        db2 = ops.colsum(dout, M, D)
-        dw2 = _weight_grad(w2, dout, a)
+        # ---- the dX chain (critical path)
         dh = torch.mm(dout, cached_operand((w2,), dt))
         ops.relu2_bwd_(h, dh)
-        db1 = ops.colsum(dh, M, F4)
-        dw1 = _weight_grad(w1, dh, xf)
         if dt == torch.bfloat16:         # N = d_model, K = d_ffn: NT product on the transposed operand copy
             dxf = ops.gemm(dh, cached_operand((w1,), dt, transpose=True), M, D, F4)
         else:
             dxf = torch.mm(dh, w1.detach())
         dx1, dln2w, dln2b = ops.layernorm_bwd(x1, dxf, dout, ln2w.detach(), mean2, rstd2)      # + residual gradient
-        # ---- attention
-        dbo = ops.colsum(dx1, M, D)
-        dwo = _weight_grad(ow, dx1, o.view(M, D))
         d_o = torch.mm(dx1, cached_operand((ow,), dt)).view(B, S, D)
         dqkv = ops.prefix_attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, d_o, lse, H, 0, prompt_len, cos_t, sin_t,
                                    stablemax)                                               # saved q,k are rotated
         ops.rope_inplace(dqkv.view(B, S, 3 * D)[:, :, :2 * D], 2 * H, rot, cos_t, sin_t, inverse=True)
         dqkv2 = dqkv.view(M, 3 * D)
-        dbqkv = ops.colsum(dqkv2, M, 3 * D)
         xa2 = xa.view(M, D)
-        dqw, dkw, dvw = _stacked_weight_grads((qw, kw, vw), dqkv2, xa2)
+
+        # ---- parameter gradients (off the critical path)
+        def param_grads(tag):
+            db2 = ops.colsum(dout, M, D, tag)
+            dw2 = _weight_grad(w2, dout, a)
+            db1 = ops.colsum(dh, M, F4, tag)
+            dw1 = _weight_grad(w1, dh, xf)
+            dbo = ops.colsum(dx1, M, D, tag)
+            dwo = _weight_grad(ow, dx1, o.view(M, D))
+            dbqkv = ops.colsum(dqkv2, M, 3 * D, tag)
+            dqw, dkw, dvw = _stacked_weight_grads((qw, kw, vw), dqkv2, xa2)
+            return db2, dw2, db1, dw1, dbo, dwo, dbqkv, dqw, dkw, dvw
+
+        if defer_dw:
+            global _join_queued
+            main = torch.cuda.current_stream(x.device)
+            side = side_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                grads = param_grads("side")
+            for t in (dout, dh, dx1, dqkv):           # temporaries of this call that the side stream still reads
+                t.record_stream(side)
+            for t in grads:
+                if t is not None:
+                    t.record_stream(main)
+            if not _join_queued:
+                _join_queued = True
+                torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+        else:
+            grads = param_grads("ws")
+        db2, dw2, db1, dw1, dbo, dwo, dbqkv, dqw, dkw, dvw = grads
         dxa = torch.mm(dqkv2, cached_operand((qw, kw, vw), dt))
         dx, dln1w, dln1b = ops.layernorm_bwd(x, dxa.view(B, S, D), dx1.view(B, S, D), ln1w.detach(), mean1, rstd1)
-        return (dx, None, None, None, None, None, None, dln1w, dln1b, dqw, dbqkv[:D], dkw, dbqkv[D:2 * D], dvw,
+        return (dx, None, None, None, None, None, None, None, dln1w, dln1b, dqw, dbqkv[:D], dkw, dbqkv[D:2 * D], dvw,
                 dbqkv[2 * D:], dwo, dbo, dln2w, dln2b, dw1, db1, dw2, db2)

@@ -90,12 +90,15 @@ class DecoderPromptLayer(nn.Module):
         cos_t, sin_t = self.rotary_emb.half_tables(S)
         return FN.DecoderLayer.apply(
             x.to(dt), cos_t, sin_t, self.nhead, self.rotary_ndims, prompt_len, self.use_stablemax,
+            getattr(self, "defer_param_grads", False),
             self.attn_norm.weight, self.attn_norm.bias, self.q.weight, self.q.bias, self.k.weight, self.k.bias,
             self.v.weight, self.v.bias, self.out.weight, self.out.bias, self.mlp_norm.weight, self.mlp_norm.bias,
             self.ffn_w1.weight, self.ffn_w1.bias, self.ffn_w2.weight, self.ffn_w2.bias)
 
 
 class SMILESDecoder(nn.Module):
+    DEFER_PARAM_GRAD_LAYERS = int(__import__("os").environ.get("MM_DEFER_DW_LAYERS", "1000"))   # all layers
+
     def __init__(self, smiles_vocab_size, nmr_vocab_size, max_seq_length=512, max_nmr_length=128, max_memory_length=128,
                  memory_dim=768, embed_dim=768, num_heads=8, num_layers=6, dropout=0.1, verbose=True, use_stablemax=False):
         super().__init__()
@@ -109,6 +112,11 @@ class SMILESDecoder(nn.Module):
                                dropout=dropout, use_rope=True, use_stablemax=use_stablemax) for _ in range(num_layers)])
         self.final_norm = nn.LayerNorm(embed_dim)
         self.out = nn.Linear(embed_dim, smiles_vocab_size)
+        # parameter-gradient GEMMs are off the dX chain: they go to a side stream, fill the tails of the main stream's
+        # kernels and, for the first layers (whose backward runs last), overlap the encoder backward's small launches
+        # (functional.DecoderLayer; measured 29.1 -> 27.8 ms per step with all layers deferred)
+        for layer in self.layers[:self.DEFER_PARAM_GRAD_LAYERS]:
+            layer.defer_param_grads = True
 
     def build_prompt(self, memory, nmr_tokens, dt):
         """Truncation rules of reference :235-243, memory_proj (:259), NMR embedding and concat (:272-282)."""

@@ -170,7 +170,7 @@ ACT_NONE, ACT_GELU, ACT_RELU2 = 0, 1, 2
 def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool = False, b_kmajor: bool = False,
          out_dtype=None, bias: Optional[Tensor] = None, pre: Optional[Tensor] = None, mul: Optional[Tensor] = None,
          act: int = ACT_NONE, gamma: Optional[Tensor] = None, rowscale: Optional[Tensor] = None, rows_per_scale: int = 0,
-         res: Optional[Tensor] = None, out: Optional[Tensor] = None, split_k: int = 1) -> Tensor:
+         res: Optional[Tensor] = None, out: Optional[Tensor] = None, split_k: int = 1, ws_tag: str = "gemm") -> Tensor:
     """out[M,N] = epilogue(A[M,K] @ B[N,K]^T).  A is [M,K] (or [K,M] if a_kmajor); B is [N,K] (or [K,N] if b_kmajor).
     Both operands are 2-D views with unit stride in the last dim."""
     for t, nm in ((A, "A"), (B, "B")):
@@ -204,19 +204,19 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool = False
     a.split_k = split_k
     if split_k > 1:
         nbytes = split_k * M * N * 4
-        ws = workspace(nbytes, A.device, "gemm")
+        ws = workspace(nbytes, A.device, ws_tag)       # a caller on a second stream passes its own tag
         a.workspace, a.workspace_bytes = L.ptr(ws), nbytes
     L.check(L.lib().mm_gemm(C.byref(a), L.cur_stream()), "mm_gemm")
     return out
 
 
-def colsum(x: Tensor, M: int, N: int) -> Tensor:
+def colsum(x: Tensor, M: int, N: int, tag: str = "ws") -> Tensor:
     if not x.is_cuda or x.stride(-1) != 1:
         raise RuntimeError("colsum: expected a GPU tensor with unit inner stride")
     x2 = x.reshape(M, N) if x.is_contiguous() else x
     out = torch.empty(N, dtype=torch.float32, device=x.device)
     nbytes = L.lib().mm_colsum_workspace(M, N)
-    ws = workspace(nbytes, x.device)
+    ws = workspace(nbytes, x.device, tag)          # a caller on a second stream passes its own tag (own buffer)
     L.check(L.lib().mm_colsum(L.ptr(x2), L.ptr(out), L.ptr(ws), nbytes, M, N, x2.stride(0), L.dtype_code(x), L.cur_stream()),
             "mm_colsum")
     return out

@@ -67,6 +67,7 @@ class OrthoGradAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         self._step += 1
+        FN.join_side_stream()
         for gi, group in enumerate(self.param_groups):
             plist = [p for p in group["params"] if p.grad is not None]
             if not plist:

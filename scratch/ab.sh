@@ -1,2 +1,2 @@
-SH="32,16,100,315,221;32,8,128,238,159"
-for v in base a b c; do echo $v; L=""; [ $v != base ] && L=$PWD/multimodal_amd/lib/libmmhip_$v.so; MM_LIB=$L timeout -k 10 200 python benchmarks/kernel_bench.py --what attnx --shapes "$SH" 2>&1 | grep prefix | cut -c 24-60,130-300 || exit 1; done
+timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread 2>&1 | tail -2 || exit 1
+for n in 1 0 1 0; do echo encside $n; MM_ENC_SIDE=$n timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-extras | cut -c1-150 || exit 1; done
