@@ -61,7 +61,7 @@ class GradBuckets:
             p.grad = p._mm_view
             p._mm_slot = (flat, off)
             off += -(-p.numel() // self.ALIGN) * self.ALIGN
-        self.buckets.append(dict(flat=flat, params=list(plist), pending=len(plist), work=None))
+        self.buckets.append(dict(flat=flat, params=list(plist), pending=len(plist), work=None, fired=set()))
 
     def zero(self):
         for b in self.buckets:
@@ -82,6 +82,10 @@ class GradBuckets:
                 src.append(g.detach().reshape(p.shape).to(p._mm_view.dtype))
             p.grad = p._mm_view
         if src:
+            if src[0].is_cuda:             # gather may run on the side stream: keep the sources' memory until it has run
+                cur = torch.cuda.current_stream(src[0].device)
+                for t in src:
+                    t.record_stream(cur)
             torch._foreach_copy_(dst, src)
         if zero:
             torch._foreach_zero_(zero)
@@ -104,22 +108,58 @@ class DataParallel:
                 self._bucket_of[p] = b
         if self.world > 1:
             self.broadcast_parameters()
+        self.optimizer = None
+        self._hooked = False
         if self.overlap:
+            self._install_hooks()
+
+    def _install_hooks(self):
+        if not self._hooked:
+            self._hooked = True
             for p in self.buckets.params:
                 p.register_post_accumulate_grad_hook(self._hook)
                 p._mm_ready = self._hook          # called by nodes that write p.grad themselves
+
+    def attach_optimizer(self, optimizer):
+        """Optimizer-in-backward: a bucket's parameters are updated (optimizer.step_subset, on the side stream) as soon
+        as the bucket's gradients are final -- after its all-reduce when world > 1 -- while backward continues.  Valid
+        for per-tensor optimizers without cross-parameter state (OrthoGradAdamW); optimizer.step() after finish() then
+        only handles what is left.  Results are identical to stepping after backward."""
+        self.optimizer = optimizer
+        self._install_hooks()
 
     def broadcast_parameters(self, src: int = 0):
         for t in list(self.module.parameters()) + list(self.module.buffers()):
             dist.broadcast(t.data, src, group=self.pg)
 
     def _launch(self, b):
-        FN.join_side_stream()                 # parameter-gradient GEMMs a node may have put on its side stream
-        self.buckets.gather(b)
-        b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        """Bucket b has all its gradients (or backward is over): complete it, reduce it, optionally update it.  On a GPU
+        all of this is issued on the side stream, after everything the main stream has been given so far (gradients
+        produced there, and the last uses of these weights in this backward)."""
+        b["launched"] = True
+        dev = b["flat"].device
+        if dev.type != "cuda":
+            self.buckets.gather(b)
+            if self.world > 1:
+                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            return
+        main, side = FN.enter_side(dev)
+        with torch.cuda.stream(side):
+            self.buckets.gather(b)
+            if self.world > 1:
+                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            if self.optimizer is not None:
+                if self.world > 1:
+                    b["work"].wait()
+                    b["flat"].mul_(1.0 / self.world)
+                    b["scaled"] = True
+                self.optimizer.step_subset(b["params"], id(b))
 
     def _hook(self, p):
         b = self._bucket_of[p]
+        if id(p) in b["fired"]:       # a node that wrote p.grad itself has reported it; autograd's own hook may follow
+            return
+        b["fired"].add(id(p))
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
@@ -129,21 +169,24 @@ class DataParallel:
         for b in self.buckets.buckets:
             b["pending"] = len(b["params"])
             b["work"] = None
+            b["launched"] = False
+            b["scaled"] = False
+            b["fired"] = set()
+        if self.optimizer is not None:
+            self.optimizer.begin_step()
 
     def finish(self):
-        """Wait for every bucket's all-reduce and average.  Parameters that received no gradient this step still
-        take part (their bucket slots are zero), so every rank issues the same collectives in the same order."""
-        if self.world == 1:
-            FN.join_side_stream()
-            for b in self.buckets.buckets:
-                self.buckets.gather(b)
-            return
+        """Complete, reduce (and average) every bucket.  Parameters that received no gradient this step still take part
+        (their bucket slots are zero), so every rank issues the same collectives in the same order."""
         for b in self.buckets.buckets:
-            if b["work"] is None:
+            if not b.get("launched", False):
                 self._launch(b)
-        for b in self.buckets.buckets:
-            b["work"].wait()
-            b["flat"].mul_(1.0 / self.world)
+        FN.join_side_stream()
+        if self.world > 1:
+            for b in self.buckets.buckets:
+                if not b.get("scaled", False):
+                    b["work"].wait()
+                    b["flat"].mul_(1.0 / self.world)
 
     def __call__(self, *a, **kw):
         return self.module(*a, **kw)

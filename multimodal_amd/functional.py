@@ -58,7 +58,6 @@ def _split_k(M: int, N: int, K: int) -> int:
 # latency-bound launches that leave most of the chip idle.  The autograd engine joins the side stream at the end of the
 # backward pass (queue_callback), and dp / the optimizer join it before they touch gradients.
 _side_streams = {}
-_ENC_SIDE = __import__("os").environ.get("MM_ENC_SIDE", "1") != "0"     # A/B switch
 _join_queued = False
 
 
@@ -70,12 +69,40 @@ def side_stream(device) -> torch.cuda.Stream:
     return s
 
 
+_main_of_side = {}
+
+
+def enter_side(device):
+    """(main, side) for a node that is about to issue work on the side stream; remembers which stream is 'main'."""
+    main = main_stream(device)
+    side = side_stream(device)
+    _main_of_side[device] = main
+    side.wait_stream(main)
+    return main, side
+
+
+def main_stream(device) -> torch.cuda.Stream:
+    """The stream the model runs on: the current stream, unless the caller is itself inside a side-stream section
+    (a gradient-ready callback fired from there), in which case the stream that section was entered from."""
+    cur = torch.cuda.current_stream(device)
+    s = _side_streams.get(device)
+    if s is not None and cur == s:
+        return _main_of_side.get(device, torch.cuda.default_stream(device))
+    return cur
+
+
+_keepalive = []      # tensors the side stream still reads (kept referenced until the main stream has joined it)
+
+
 def join_side_stream() -> None:
     """Make the current stream wait for every side-stream gradient launch issued so far."""
     global _join_queued
     _join_queued = False
+    # memory released from here on returns to the main stream's pool, and the main stream now waits for the side
+    # stream before running anything new: no reuse can overtake a side-stream reader
+    _keepalive.clear()
     for dev, s in _side_streams.items():
-        torch.cuda.current_stream(dev).wait_stream(s)
+        main_stream(dev).wait_stream(s)
 
 
 
@@ -133,25 +160,22 @@ class ConvNeXtBlock(torch.autograd.Function):
         dz, dgamma, db2 = ops.layerscale_bwd(dout, z, gvec, dp_scale, Ln)
         w1c, w2c = cached_operand((w1,), dt), cached_operand((w2,), dt)
         dh = ops.gemm(dz, w2c, M, 4 * Cc, Cc, b_kmajor=True, mul=h, act=ops.ACT_GELU)
+        dxn = ops.gemm(dh, w1c, M, Cc, 4 * Cc, b_kmajor=True)        # last use of the block's weights (see DecoderLayer)
         # weight / bias gradients on the side stream (see DecoderLayer): the dX chain below does not wait for them
         global _join_queued
-        main = torch.cuda.current_stream(x.device)
-        side = side_stream(x.device) if _ENC_SIDE else main
-        side.wait_stream(main)
+        main, side = enter_side(x.device)
         with torch.cuda.stream(side):
             dw2 = ops.gemm(dz, a, Cc, 4 * Cc, M, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32,
                            split_k=_split_k(Cc, 4 * Cc, M), ws_tag="gemm_side")
             db1 = ops.colsum(dh, M, 4 * Cc, "side")
             dw1 = ops.gemm(dh, xn.view(M, Cc), 4 * Cc, Cc, M, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32,
                            split_k=_split_k(4 * Cc, Cc, M), ws_tag="gemm_side")
-        for t in (dz, dh):
-            t.record_stream(side)
+        _keepalive.append((dz, dh, a, xn))     # incl. saved activations (freed when this node is released)
         for t in (dw2, db1, dw1):
             t.record_stream(main)
         if not _join_queued:
             _join_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
-        dxn = ops.gemm(dh, w1c, M, Cc, 4 * Cc, b_kmajor=True)
         dx, ddw, ddb, dlw, dlb = ops.dwconv7_ln_bwd(x, dxn.view(B, Ln, Cc), dout.view(B, Ln, Cc), dw_w.detach(),
                                                     dw_b.detach(), ln_w.detach(), mean, rstd)
         return dx, ddw, ddb, dlw, dlb, dw1, db1, dw2, db2, (dgamma if gamma is not None else None), None
@@ -427,6 +451,9 @@ class DecoderLayer(torch.autograd.Function):
         ops.rope_inplace(dqkv.view(B, S, 3 * D)[:, :, :2 * D], 2 * H, rot, cos_t, sin_t, inverse=True)
         dqkv2 = dqkv.view(M, 3 * D)
         xa2 = xa.view(M, D)
+        # last use of this layer's weights: issued before the parameter gradients, because their completion may trigger
+        # the optimizer update of these very weights (dp.DataParallel.attach_optimizer)
+        dxa = torch.mm(dqkv2, cached_operand((qw, kw, vw), dt))
 
         # ---- parameter gradients (off the critical path)
         def param_grads(tag):
@@ -442,13 +469,12 @@ class DecoderLayer(torch.autograd.Function):
 
         if defer_dw:
             global _join_queued
-            main = torch.cuda.current_stream(x.device)
-            side = side_stream(x.device)
-            side.wait_stream(main)
+            main, side = enter_side(x.device)
             with torch.cuda.stream(side):
                 grads = param_grads("side")
-            for t in (dout, dh, dx1, dqkv):           # temporaries of this call that the side stream still reads
-                t.record_stream(side)
+            # everything the side stream still reads: this call's temporaries and the saved activations, whose memory
+            # the allocator would otherwise hand back to the main stream as soon as this node is released
+            _keepalive.append((dout, dh, dx1, dqkv, a, xf, o, xa))
             for t in grads:
                 if t is not None:
                     t.record_stream(main)
@@ -458,7 +484,6 @@ class DecoderLayer(torch.autograd.Function):
         else:
             grads = param_grads("ws")
         db2, dw2, db1, dw1, dbo, dwo, dbqkv, dqw, dkw, dvw = grads
-        dxa = torch.mm(dqkv2, cached_operand((qw, kw, vw), dt))
         dx, dln1w, dln1b = ops.layernorm_bwd(x, dxa.view(B, S, D), dx1.view(B, S, D), ln1w.detach(), mean1, rstd1)
         return (dx, None, None, None, None, None, None, None, dln1w, dln1b, dqw, dbqkv[:D], dkw, dbqkv[D:2 * D], dvw,
                 dbqkv[2 * D:], dwo, dbo, dln2w, dln2b, dw1, db1, dw2, db2)

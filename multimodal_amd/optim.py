@@ -34,7 +34,7 @@ class OrthoGradAdamW(torch.optim.Optimizer):
     def _key(plist, shadows):
         return tuple((p.data_ptr(), p.grad.data_ptr(), 0 if s is None else s.data_ptr()) for p, s in zip(plist, shadows))
 
-    def _build(self, gi, plist, shadows):
+    def _build(self, slot, plist, shadows):
         dev = plist[0].device
         descs = (ParamDesc * len(plist))()
         ct, co, tcs = [], [], [0]
@@ -57,8 +57,52 @@ class OrthoGradAdamW(torch.optim.Optimizer):
             descs=torch.from_numpy(raw.copy()).to(dev),
             ct=torch.tensor(ct, dtype=torch.int32, device=dev), co=torch.tensor(co, dtype=torch.int64, device=dev),
             tcs=torch.tensor(tcs, dtype=torch.int32, device=dev), n_tensors=len(plist), n_chunks=len(ct))
-        self._tables[gi] = tab
+        self._tables[slot] = tab
         return tab
+
+    def _run(self, slot, group, plist):
+        """One OrthoGrad+AdamW launch sequence over plist with group's hyper-parameters, on the current stream."""
+        for p in plist:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+                raise RuntimeError("OrthoGradAdamW: float32 contiguous GPU parameters and gradients only")
+        # bf16 GEMM-operand copies the model keeps of these parameters (functional.cached_operand): the update
+        # refreshes them in the same pass, so no cast kernels run in the next forward
+        shadows = [FN.shadow_of(p) for p in plist]
+        tab = self._tables.get(slot)
+        if tab is None or tab["key"] != self._key(plist, shadows):
+            tab = self._build(slot, plist, shadows)
+        nbytes = L.lib().mm_orthograd_adamw_workspace(tab["n_tensors"], tab["n_chunks"])
+        ws = ops.workspace(nbytes, plist[0].device, "optim")
+        b1, b2 = group["betas"]
+        L.check(L.lib().mm_orthograd_adamw(L.ptr(tab["descs"]), L.ptr(tab["ct"]), L.ptr(tab["co"]), L.ptr(tab["tcs"]),
+                                           tab["n_tensors"], tab["n_chunks"], CHUNK, group["lr"], b1, b2, group["eps"],
+                                           group["weight_decay"], self._step, group["ortho_eps"], int(group["rescale"]),
+                                           int(group["ortho"]), L.ptr(ws), nbytes, L.cur_stream()), "mm_orthograd_adamw")
+        # the kernel writes through raw pointers: tell autograd (and functional.cached_operand) the values moved
+        torch.autograd.graph.increment_version(plist)
+        FN.shadows_written([p for p, s in zip(plist, shadows) if s is not None])
+
+    # ---- optimizer-in-backward (driven by dp.DataParallel.attach_optimizer): OrthoGrad and AdamW are per-tensor, so a
+    # bucket of parameters can be updated as soon as its gradients are final, while backward continues on other layers
+    def begin_step(self):
+        self._step += 1
+        self._begun = True
+        self._done = set()
+        self._group_of = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
+
+    @torch.no_grad()
+    def step_subset(self, params, tag):
+        """Update `params` now (their .grad must be final), on the current stream.  begin_step() opened the step."""
+        if not getattr(self, "_begun", False):
+            raise RuntimeError("OrthoGradAdamW.step_subset outside begin_step()/step()")
+        by_group = {}
+        for p in params:
+            gi = self._group_of.get(id(p))
+            if gi is not None and p.grad is not None and id(p) not in self._done:
+                by_group.setdefault(gi, []).append(p)
+        for gi, plist in by_group.items():
+            self._run(("subset", tag, gi), self.param_groups[gi], plist)
+            self._done.update(id(p) for p in plist)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -66,29 +110,15 @@ class OrthoGradAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        self._step += 1
+        begun = getattr(self, "_begun", False)
+        if not begun:
+            self._step += 1
+        done = self._done if begun else ()
         FN.join_side_stream()
         for gi, group in enumerate(self.param_groups):
-            plist = [p for p in group["params"] if p.grad is not None]
-            if not plist:
-                continue
-            for p in plist:
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
-                    raise RuntimeError("OrthoGradAdamW: float32 contiguous GPU parameters and gradients only")
-            # bf16 GEMM-operand copies the model keeps of these parameters (functional.cached_operand): the update
-            # refreshes them in the same pass, so no cast kernels run in the next forward
-            shadows = [FN.shadow_of(p) for p in plist]
-            tab = self._tables.get(gi)
-            if tab is None or tab["key"] != self._key(plist, shadows):
-                tab = self._build(gi, plist, shadows)
-            nbytes = L.lib().mm_orthograd_adamw_workspace(tab["n_tensors"], tab["n_chunks"])
-            ws = ops.workspace(nbytes, plist[0].device, "optim")
-            b1, b2 = group["betas"]
-            L.check(L.lib().mm_orthograd_adamw(L.ptr(tab["descs"]), L.ptr(tab["ct"]), L.ptr(tab["co"]), L.ptr(tab["tcs"]),
-                                               tab["n_tensors"], tab["n_chunks"], CHUNK, group["lr"], b1, b2, group["eps"],
-                                               group["weight_decay"], self._step, group["ortho_eps"], int(group["rescale"]),
-                                               int(group["ortho"]), L.ptr(ws), nbytes, L.cur_stream()), "mm_orthograd_adamw")
-            # the kernel writes through raw pointers: tell autograd (and functional.cached_operand) the values moved
-            torch.autograd.graph.increment_version(plist)
-            FN.shadows_written([p for p, s in zip(plist, shadows) if s is not None])
+            plist = [p for p in group["params"] if p.grad is not None and id(p) not in done]
+            if plist:
+                self._run(("all" if not begun else "rest", gi), group, plist)
+        self._begun = False
+        self._done = set()
         return loss

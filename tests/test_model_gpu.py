@@ -135,6 +135,42 @@ def test_bucket_direct_weight_grads_equal_autograd(golden_meta, dtype, monkeypat
     assert l1 != l0 and abs(loss_of(m2).item() - l1) < 1e-6 * abs(l1)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_optimizer_in_backward_equals_step_after_backward(golden_meta, dtype):
+    """dp.attach_optimizer updates each gradient bucket on the side stream while backward continues; three steps must
+    leave exactly the weights (and bf16 operand copies, seen through the next forward) of the plain sequence."""
+    from multimodal_amd.dp import DataParallel
+    from multimodal_amd.optim import OrthoGradAdamW
+    case = golden_meta["cases"]["d100_sm"]
+    ir, nmr, tgt = case_inputs(case)
+    tg = tgt.to(DEV)
+
+    def run(overlap):
+        torch.manual_seed(7)                                       # DropPath draws
+        m = build(case, dtype).train()
+        dp = DataParallel(m, bucket_bytes=1 << 20)                 # several buckets even for this small model
+        opt = OrthoGradAdamW(m.parameters(), lr=3e-3, weight_decay=0.01, ortho_eps=1e-8)
+        if overlap:
+            dp.attach_optimizer(opt)
+        losses = []
+        for _ in range(3):
+            dp.zero_grad()
+            logits = m(nmr.to(DEV), ir.to(DEV), tg[:, :-1], None)
+            loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.size(-1)), tg[:, 1:].reshape(-1), ignore_index=0)
+            loss.backward()
+            dp.finish()
+            opt.step()
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        return losses, dict((k, v.clone()) for k, v in m.state_dict().items())
+
+    l0, s0 = run(False)
+    l1, s1 = run(True)
+    assert l0 == l1
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
 def test_train_mode_droppath_vs_reference_golden(golden_meta, monkeypatch):
     """DropPath draws torch.rand((B,1,1)) per block in block order (convnext.py:15); the draws are taken from the
     CPU generator here so the stream equals the one the golden vector was produced with."""
