@@ -91,14 +91,27 @@ class GradBuckets:
             torch._foreach_zero_(zero)
 
 
+class _Done:
+    """Stand-in for a collective's work handle when the collective has already completed."""
+
+    def wait(self):
+        return True
+
+
 class DataParallel:
     """Wraps a replicated module.  Usage per step:  dp.zero_grad(); loss.backward(); dp.finish(); optimizer.step().
-    Gradients are complete (all in their bucket slots, averaged over ranks) only after finish()."""
+    Gradients are complete (all in their bucket slots, averaged over ranks) only after finish().
+    host_staged: run the collectives on host copies of GPU tensors -- for backends without (reliable) device support;
+    defaults to True when the process group's backend is gloo, False for nccl (= RCCL)."""
 
-    def __init__(self, module: torch.nn.Module, process_group=None, bucket_bytes: int = 128 << 20, overlap: bool = True):
+    def __init__(self, module: torch.nn.Module, process_group=None, bucket_bytes: int = 128 << 20, overlap: bool = True,
+                 host_staged: Optional[bool] = None):
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if host_staged is None:
+            host_staged = dist.is_initialized() and dist.get_backend(process_group) == "gloo"
+        self.host_staged = host_staged
         adjacent = [g for m in module.modules() if hasattr(m, "stacked_grad_groups") for g in m.stacked_grad_groups()]
         self.buckets = GradBuckets(list(module.parameters()), bucket_bytes, adjacent=adjacent)
         self.overlap = overlap and self.world > 1
@@ -130,7 +143,21 @@ class DataParallel:
 
     def broadcast_parameters(self, src: int = 0):
         for t in list(self.module.parameters()) + list(self.module.buffers()):
-            dist.broadcast(t.data, src, group=self.pg)
+            if t.is_cuda and self.host_staged:
+                h = t.data.cpu()
+                dist.broadcast(h, src, group=self.pg)
+                t.data.copy_(h)
+            else:
+                dist.broadcast(t.data, src, group=self.pg)
+
+    def _all_reduce(self, flat):
+        """Sum `flat` over the ranks, ordered after the current stream's work; returns a handle with wait()."""
+        if flat.is_cuda and self.host_staged:
+            h = flat.cpu()                       # synchronises with the current stream
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+            flat.copy_(h)
+            return _Done()
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def _launch(self, b):
         """Bucket b has all its gradients (or backward is over): complete it, reduce it, optionally update it.  On a GPU
@@ -141,13 +168,13 @@ class DataParallel:
         if dev.type != "cuda":
             self.buckets.gather(b)
             if self.world > 1:
-                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                b["work"] = self._all_reduce(b["flat"])
             return
         main, side = FN.enter_side(dev)
         with torch.cuda.stream(side):
             self.buckets.gather(b)
             if self.world > 1:
-                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                b["work"] = self._all_reduce(b["flat"])
             if self.optimizer is not None:
                 if self.world > 1:
                     b["work"].wait()
