@@ -109,6 +109,9 @@ extern "C" int mm_argmax_rows(const void* logits, int64_t* out, int64_t rows, in
 //   pass 1  per chunk: partial (w.w, w.g, g.g)        -> finalize per tensor: proj = w.g/(w.w+eps),
 //           |g_orth|^2 = g.g - 2 proj w.g + proj^2 w.w, scale = |g| / (|g_orth| + eps)   (rescale)
 //   pass 2  g <- (g - proj w) * scale;  AdamW update of p, m, v with that g.
+//   The closed form of |g_orth|^2 cancels when g is nearly parallel to w (tiny tensors, scalars): finalize flags a
+//   tensor whose |g_orth|^2 < 1% of |g|^2 and og_exact_k then sums (g - proj w)^2 element by element for the flagged
+//   tensors only (its blocks of every other tensor exit at once); pass 2 takes the scale from those sums.
 // Tables (device memory, built once by the caller): descs[n_tensors], chunk_tensor[n_chunks],
 // chunk_off[n_chunks], tensor_chunk_start[n_tensors+1].  Deterministic (fixed-order sums, f64 finalize).
 // ------------------------------------------------------------------------------------------------
@@ -119,7 +122,20 @@ __global__ __launch_bounds__(256) void og_reduce_k(const mm_param_desc* __restri
     const long off = chunk_off[blockIdx.x];
     const long end = min(d.n, off + (long)chunk_elems);
     float ww = 0.f, wg = 0.f, gg = 0.f;
-    for (long i = off + threadIdx.x; i < end; i += 256) {
+    long i0 = off;
+    if (((((uintptr_t)d.p) | ((uintptr_t)d.g)) & 15) == 0) {          // 16 B per lane; chunk offsets are multiples of 4
+        const long vend = off + ((end - off) & ~3L);
+#pragma unroll 4
+        for (long i = off + threadIdx.x * 4; i < vend; i += 1024) {
+            const float4 w = *(const float4*)(d.p + i), g = *(const float4*)(d.g + i);
+            ww = fmaf(w.x, w.x, ww); wg = fmaf(w.x, g.x, wg); gg = fmaf(g.x, g.x, gg);
+            ww = fmaf(w.y, w.y, ww); wg = fmaf(w.y, g.y, wg); gg = fmaf(g.y, g.y, gg);
+            ww = fmaf(w.z, w.z, ww); wg = fmaf(w.z, g.z, wg); gg = fmaf(g.z, g.z, gg);
+            ww = fmaf(w.w, w.w, ww); wg = fmaf(w.w, g.w, wg); gg = fmaf(g.w, g.w, gg);
+        }
+        i0 = vend;
+    }
+    for (long i = i0 + threadIdx.x; i < end; i += 256) {
         const float w = d.p[i], g = d.g[i];
         ww = fmaf(w, w, ww); wg = fmaf(w, g, wg); gg = fmaf(g, g, gg);
     }
@@ -129,45 +145,105 @@ __global__ __launch_bounds__(256) void og_reduce_k(const mm_param_desc* __restri
     if (threadIdx.x < 3) part[(long)blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
 __global__ void og_finalize_k(const float* __restrict__ part, const int* __restrict__ tcs, int n_tensors, float ortho_eps,
-                              int rescale, float* __restrict__ coef) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= n_tensors) return;
+                              int rescale, float* __restrict__ coef, int* __restrict__ flag) {
+    // one wave per tensor: lanes stride over the tensor's chunk partials, fixed-order butterfly in double
+    const int t = blockIdx.x;
     double ww = 0, wg = 0, gg = 0;
-    for (int c = tcs[t]; c < tcs[t + 1]; c++) { ww += part[(long)c * 3]; wg += part[(long)c * 3 + 1]; gg += part[(long)c * 3 + 2]; }
-    const double proj = wg / (ww + (double)ortho_eps);
-    double scale = 1.0;
+    for (int c = tcs[t] + threadIdx.x; c < tcs[t + 1]; c += 64) { ww += part[(long)c * 3]; wg += part[(long)c * 3 + 1]; gg += part[(long)c * 3 + 2]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ww += __shfl_xor(ww, o); wg += __shfl_xor(wg, o); gg += __shfl_xor(gg, o); }
+    if (threadIdx.x != 0) return;
+    // the sums are rounded to float and combined in float arithmetic in the reference's order (ortho_grad.py:69-77), so
+    // that a tensor whose sums are exact (a scalar parameter) gets bit-identical coefficients
+    const float proj = (float)wg / ((float)ww + ortho_eps);
+    const float gnorm = sqrtf((float)gg);
+    float scale = 1.f;
+    int fl = 0;
     if (rescale) {
-        double go2 = gg - 2.0 * proj * wg + proj * proj * ww;
+        double go2 = gg - 2.0 * (double)proj * wg + (double)proj * (double)proj * ww;
+        if (go2 < 0.01 * gg) fl = 1;
         if (go2 < 0) go2 = 0;
-        scale = sqrt(gg) / (sqrt(go2) + (double)ortho_eps);
+        scale = gnorm / (sqrtf((float)go2) + ortho_eps);
     }
-    coef[2 * t] = (float)proj; coef[2 * t + 1] = (float)scale;
+    coef[3 * t] = proj; coef[3 * t + 1] = scale; coef[3 * t + 2] = gnorm;
+    flag[t] = fl;
+}
+__global__ __launch_bounds__(256) void og_exact_k(const mm_param_desc* __restrict__ descs, const int* __restrict__ chunk_tensor,
+                                                 const long* __restrict__ chunk_off, int chunk_elems, const float* __restrict__ coef,
+                                                 const int* __restrict__ flag, float* __restrict__ part2) {
+    __shared__ float red[4];
+    const int t = chunk_tensor[blockIdx.x];
+    if (!flag[t]) return;
+    const mm_param_desc d = descs[t];
+    const long off = chunk_off[blockIdx.x];
+    const long end = min(d.n, off + (long)chunk_elems);
+    const float proj = coef[3 * t];
+    float s = 0.f;
+    for (long i = off + threadIdx.x; i < end; i += 256) {
+        const float go = d.g[i] - proj * d.p[i];
+        s = fmaf(go, go, s);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part2[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 __global__ __launch_bounds__(256) void og_adamw_k(const mm_param_desc* __restrict__ descs, const int* __restrict__ chunk_tensor,
                                                  const long* __restrict__ chunk_off, int chunk_elems, const float* __restrict__ coef,
+                                                 const int* __restrict__ flag, const float* __restrict__ part2,
+                                                 const int* __restrict__ tcs, float ortho_eps,
                                                  float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s) {
     const int t = chunk_tensor[blockIdx.x];
     const mm_param_desc d = descs[t];
     const long off = chunk_off[blockIdx.x];
     const long end = min(d.n, off + (long)chunk_elems);
-    const float proj = coef ? coef[2 * t] : 0.f, scale = coef ? coef[2 * t + 1] : 1.f;
+    const float proj = coef ? coef[3 * t] : 0.f;
+    float scale = coef ? coef[3 * t + 1] : 1.f;
+    if (coef && flag[t]) {                     // ill-conditioned closed form: |g_orth| from the element-wise sums
+        double go2 = 0;
+        for (int c = tcs[t]; c < tcs[t + 1]; c++) go2 += part2[c];
+        scale = coef[3 * t + 2] / (sqrtf((float)go2) + ortho_eps);
+    }
     const float step_size = lr / bc1;
-    for (long i = off + threadIdx.x; i < end; i += 256) {
-        float w = d.p[i];
-        float g = d.g[i];
-        if (coef) { g = (g - proj * w) * scale; d.g[i] = g; }
-        w *= 1.f - lr * wd;
-        const float m = b1 * d.m[i] + (1.f - b1) * g;
-        const float v = b2 * d.v[i] + (1.f - b2) * g * g;
-        d.m[i] = m; d.v[i] = v;
+    const float decay = 1.f - lr * wd, rb1 = 1.f - b1, rb2 = 1.f - b2;
+    auto upd = [&](float& w, float& g, float& m, float& v) {
+        if (coef) g = (g - proj * w) * scale;
+        w *= decay;
+        m = b1 * m + rb1 * g;
+        v = b2 * v + rb2 * g * g;
         const float denom = sqrtf(v) / bc2s + eps;
-        const float wn = w - step_size * (m / denom);
-        d.p[i] = wn;
-        if (d.w16) ((bf16*)d.w16)[i] = __float2bfloat16(wn);
+        w = w - step_size * (m / denom);
+    };
+    long i0 = off;
+    if (((((uintptr_t)d.p) | ((uintptr_t)d.g) | ((uintptr_t)d.m) | ((uintptr_t)d.v)) & 15) == 0 && (((uintptr_t)d.w16) & 7) == 0) {
+        const long vend = off + ((end - off) & ~3L);
+#pragma unroll 2
+        for (long i = off + threadIdx.x * 4; i < vend; i += 1024) {
+            // once-touched streams: non-temporal (the weights and their bf16 copies are read again by the next forward)
+            float w[4], g[4], m[4], v[4];
+            VecIO<float, 4>::load(d.p + i, w); VecIO<float, 4>::load_nt(d.g + i, g);
+            VecIO<float, 4>::load_nt(d.m + i, m); VecIO<float, 4>::load_nt(d.v + i, v);
+#pragma unroll
+            for (int j = 0; j < 4; j++) upd(w[j], g[j], m[j], v[j]);
+            if (coef) VecIO<float, 4>::store_nt(d.g + i, g);
+            VecIO<float, 4>::store_nt(d.m + i, m); VecIO<float, 4>::store_nt(d.v + i, v);
+            VecIO<float, 4>::store(d.p + i, w);
+            if (d.w16) {
+                VecIO<bf16, 4>::store((bf16*)d.w16 + i, w);
+            }
+        }
+        i0 = vend;
+    }
+    for (long i = i0 + threadIdx.x; i < end; i += 256) {
+        float w = d.p[i], g = d.g[i], m = d.m[i], v = d.v[i];
+        upd(w, g, m, v);
+        if (coef) d.g[i] = g;
+        d.m[i] = m; d.v[i] = v; d.p[i] = w;
+        if (d.w16) ((bf16*)d.w16)[i] = __float2bfloat16(w);
     }
 }
 extern "C" size_t mm_orthograd_adamw_workspace(int64_t n_tensors, int64_t n_chunks) {
-    return (n_tensors > 0 && n_chunks > 0) ? (size_t)(3 * n_chunks + 2 * n_tensors) * sizeof(float) : 0;
+    return (n_tensors > 0 && n_chunks > 0) ? (size_t)(4 * n_chunks + 4 * n_tensors) * sizeof(float) : 0;
 }
 extern "C" int mm_orthograd_adamw(const mm_param_desc* descs, const int32_t* chunk_tensor, const int64_t* chunk_off,
                                   const int32_t* tensor_chunk_start, int64_t n_tensors, int64_t n_chunks, int64_t chunk_elems,
@@ -179,17 +255,24 @@ extern "C" int mm_orthograd_adamw(const mm_param_desc* descs, const int32_t* chu
     MM_CHECK(workspace_bytes >= mm_orthograd_adamw_workspace(n_tensors, n_chunks), "orthograd_adamw: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
-    float* coef = part + 3 * n_chunks;
+    float* part2 = part + 3 * n_chunks;
+    float* coef = part2 + n_chunks;
+    int* flag = (int*)(coef + 3 * n_tensors);
     if (do_ortho) {
         hipLaunchKernelGGL(og_reduce_k, dim3((unsigned)n_chunks), dim3(256), 0, st, descs, (const int*)chunk_tensor, (const long*)chunk_off, (int)chunk_elems, part);
         MM_LAUNCH_CHECK();
-        hipLaunchKernelGGL(og_finalize_k, dim3((unsigned)cdiv(n_tensors, 64)), dim3(64), 0, st, part, (const int*)tensor_chunk_start, (int)n_tensors, ortho_eps, rescale, coef);
+        hipLaunchKernelGGL(og_finalize_k, dim3((unsigned)n_tensors), dim3(64), 0, st, part, (const int*)tensor_chunk_start, (int)n_tensors, ortho_eps, rescale, coef, flag);
         MM_LAUNCH_CHECK();
+        if (rescale) {
+            hipLaunchKernelGGL(og_exact_k, dim3((unsigned)n_chunks), dim3(256), 0, st, descs, (const int*)chunk_tensor, (const long*)chunk_off, (int)chunk_elems,
+                               (const float*)coef, (const int*)flag, part2);
+            MM_LAUNCH_CHECK();
+        }
     }
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(og_adamw_k, dim3((unsigned)n_chunks), dim3(256), 0, st, descs, (const int*)chunk_tensor, (const long*)chunk_off, (int)chunk_elems,
-                       do_ortho ? coef : nullptr, lr, beta1, beta2, adam_eps, weight_decay, bc1, bc2s);
+                       do_ortho ? coef : nullptr, (const int*)flag, (const float*)part2, (const int*)tensor_chunk_start, ortho_eps, lr, beta1, beta2, adam_eps, weight_decay, bc1, bc2s);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }

@@ -122,3 +122,19 @@ class OrthoGradAdamW(torch.optim.Optimizer):
         self._begun = False
         self._done = set()
         return loss
+
+
+def OrthoGrad(params, base_optimizer_cls=torch.optim.AdamW, eps: float = 1e-30, rescale: bool = True, **base_optimizer_args):
+    """Constructor with the reference's signature (ortho_grad.py:20-46) for train scripts that build
+    ``OrthoGrad(model.parameters(), base_optimizer_cls=optim.AdamW, eps=..., rescale=..., lr=..., ...)``
+    (train_autoregressive.py:698-704).  The reference keeps ONE 'eps' entry per parameter group, shared by the
+    projection and the wrapped AdamW (the base optimizer's own default never replaces it), and so does this.
+    Only AdamW is fused here; any other base class is an error, not a fallback."""
+    if base_optimizer_cls is not torch.optim.AdamW:
+        raise NotImplementedError("multimodal_amd.optim.OrthoGrad: only base_optimizer_cls=torch.optim.AdamW is implemented")
+    extra = set(base_optimizer_args) - {"lr", "betas", "weight_decay"}
+    if extra:
+        raise TypeError(f"multimodal_amd.optim.OrthoGrad: unsupported AdamW arguments {sorted(extra)}")
+    return OrthoGradAdamW(params, lr=base_optimizer_args.get("lr", 1e-3), betas=base_optimizer_args.get("betas", (0.9, 0.999)),
+                          eps=eps, weight_decay=base_optimizer_args.get("weight_decay", 1e-2), ortho=True, ortho_eps=eps,
+                          rescale=rescale)

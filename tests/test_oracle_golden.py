@@ -119,3 +119,24 @@ def test_kv_cache_legality_on_oracle(golden_meta):
         full = restate.smiles_decoder(sd, tgt[:, :12], mem, nmr, cfg)
         part = restate.smiles_decoder(sd, tgt[:, :5], mem, nmr, cfg)
     assert rel_err(part, full[:, :5]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["cfg", "norescale", "eps30"])
+def test_orthograd_adamw_restatement_matches_reference(name):
+    """oracle.restate.orthograd_project_ + torch AdamW (sharing the group's eps, ortho_grad.py:42-46) against the
+    parameters the reference's OrthoGrad(AdamW) produced (tests/golden/optim.npz, oracle/gen_golden_optim.py)."""
+    import numpy as np
+    from oracle import restate
+    from oracle.gen_golden_optim import STEPS, VARIANTS, params_and_grads
+    gold = np.load(os.path.join(GOLDEN, "optim.npz"), allow_pickle=False)
+    eps, rescale, lr, betas, wd = VARIANTS[name]
+    ps, gs = params_and_grads()
+    ps = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = torch.optim.AdamW(ps, lr=lr, betas=betas, eps=eps, weight_decay=wd)
+    for t in range(STEPS):
+        for p, g in zip(ps, gs[t]):
+            p.grad = None if g is None else g.clone()
+        restate.orthograd_project_(ps, eps=eps, rescale=rescale)
+        opt.step()
+        for i, p in enumerate(ps):
+            assert torch.equal(p.detach(), torch.from_numpy(gold[f"{name}.step{t}.p{i}"])), (t, i)
