@@ -73,6 +73,13 @@ int mm_layernorm_bwd(const void* x, const void* dy, const void* dres /*nullable,
                      const float* w, const float* mean, const float* rstd, void* dx, float* dw, float* db,
                      void* workspace, size_t workspace_bytes, int64_t G, int64_t Lin, int64_t Lout, int64_t C,
                      int dtype, void* stream);
+/* Pre-LN residual block  y = x + Linear(...LN(x)...)  (models/transformer_decoder.py:122-127,:157-163): the same backward,
+ * dx = dres + LN'(dy), which also returns dres_sum[c] = sum_rows dres and dx_sum[c] = sum_rows dx -- autograd's bias
+ * gradients of the Linear after the residual add and of the Linear that produced x -- without a pass of their own.
+ * Wide rows only: C > 512 and C % 4 == 0; workspace as mm_layernorm_bwd_workspace(rows, C). */
+int mm_layernorm_bwd_sums(const void* x, const void* dy, const void* dres, const float* w, const float* mean,
+                          const float* rstd, void* dx, float* dw, float* db, float* dres_sum, float* dx_sum,
+                          void* workspace, size_t workspace_bytes, int64_t rows, int64_t C, int dtype, void* stream);
 
 /* ---- GEMM family (MFMA; bf16 or exact-f32 matrix cores) -----------------------------------
  * out[M][N] = epilogue( A[M][K] . B^T ), B given as [N][K] (nn.Linear weight layout).
@@ -168,6 +175,10 @@ int mm_argmax_rows(const void* logits, int64_t* out, int64_t rows, int64_t V, in
  * dh = da * 2*relu(h); dh may alias da. */
 int mm_relu2_fwd(const void* h, void* a, int64_t n, int dtype, void* stream);
 int mm_relu2_bwd(const void* h, const void* da, void* dh, int64_t n, int dtype, void* stream);
+/* relu^2 backward over [M][N] plus colsum[n] = sum_m dh[m][n], autograd's gradient of the bias of the Linear that produced h
+ * (models/transformer_decoder.py:161), in the same pass; workspace as mm_colsum_workspace(M, N); rows 16-byte aligned. */
+int mm_relu2_bwd_colsum(const void* h, const void* da, void* dh, float* colsum, void* workspace, size_t workspace_bytes,
+                        int64_t M, int64_t N, int dtype, void* stream);
 /* out[c][r] = (out_dtype) in[r][c]: transposed compute-dtype copy of an f32 [R][C] weight (row stride ldo >= R), the
  * operand that makes dX = dY . W (autograd of nn.Linear, models/transformer_decoder.py:159-163) K-contiguous. */
 int mm_cast_transpose(const float* in, void* out, int64_t R, int64_t C, int64_t ldo, int out_dtype, void* stream);

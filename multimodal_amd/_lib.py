@@ -49,6 +49,7 @@ _SIGNATURES = {
     "mm_layernorm_fwd": (i32, [vp] * 6 + [i64, i64, i64, i64, f32, i32, vp]),
     "mm_layernorm_bwd_workspace": (sz, [i64, i64]),
     "mm_layernorm_bwd": (i32, [vp] * 9 + [vp, sz, i64, i64, i64, i64, i32, vp]),
+    "mm_layernorm_bwd_sums": (i32, [vp] * 11 + [vp, sz, i64, i64, i32, vp]),
     "mm_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "mm_colsum_workspace": (sz, [i64, i64]),
     "mm_colsum": (i32, [vp, vp, vp, sz, i64, i64, i64, i32, vp]),
@@ -63,6 +64,7 @@ _SIGNATURES = {
     "mm_argmax_rows": (i32, [vp, vp, i64, i64, i64, i32, vp]),
     "mm_relu2_fwd": (i32, [vp, vp, i64, i32, vp]),
     "mm_relu2_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
+    "mm_relu2_bwd_colsum": (i32, [vp, vp, vp, vp, vp, sz, i64, i64, i32, vp]),
     "mm_cast_transpose": (i32, [vp, vp, i64, i64, i64, i32, vp]),
     "mm_orthograd_adamw_workspace": (sz, [i64, i64]),
     "mm_orthograd_adamw": (i32, [vp, vp, vp, vp, i64, i64, i64, f32, f32, f32, f32, f32, i64, f32, i32, i32, vp, sz, vp]),

@@ -410,3 +410,70 @@ extern "C" int mm_colsum(const void* x, float* out, void* workspace, size_t work
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// relu^2 backward fused with the bias gradient of the Linear in front of it (models/transformer_decoder.py:161):
+//   dh = da * 2*max(h,0)  (dh may alias da),   colsum[n] = sum_m dh[m][n]  (of the values as stored)
+// Same block shape and two-stage fixed-order reduction as mm_colsum: the [M][N] tensor is read once instead of twice.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void relu2_bwd_colsum_k(const T* __restrict__ h, const T* da, T* dh, float* __restrict__ part,
+                                                          int M, int N, int rows_per_chunk) {
+    __shared__ float red[8][32 * VEC + 1];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int n0 = (blockIdx.x * 32 + cl) * VEC;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) s[j] = 0.f;
+    if (n0 < N) {
+#pragma unroll 4
+        for (int r = r0 + rg; r < r1; r += 8) {
+            float hv[VEC], gv[VEC];
+            VecIO<T, VEC>::load(h + (long)r * N + n0, hv);
+            VecIO<T, VEC>::load(da + (long)r * N + n0, gv);
+#pragma unroll
+            for (int j = 0; j < VEC; j++) {
+                gv[j] = to_f(from_f<T>(gv[j] * (2.f * fmaxf(hv[j], 0.f))));
+                s[j] += gv[j];
+            }
+            VecIO<T, VEC>::store(dh + (long)r * N + n0, gv);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) red[rg][cl * VEC + j] = s[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 32 * VEC; c += 256) {
+        const int n = blockIdx.x * 32 * VEC + c;
+        if (n < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; g++) t += red[g][c];
+            part[(long)blockIdx.y * N + n] = t;
+        }
+    }
+}
+extern "C" int mm_relu2_bwd_colsum(const void* h, const void* da, void* dh, float* colsum, void* workspace,
+                                   size_t workspace_bytes, int64_t M, int64_t N, int dtype, void* stream) {
+    MM_CHECK(h && da && dh && colsum && workspace, "relu2_bwd_colsum: null pointer");
+    MM_CHECK(M > 0 && N > 0, "relu2_bwd_colsum: bad shape");
+    MM_CHECK(workspace_bytes >= mm_colsum_workspace(M, N), "relu2_bwd_colsum: workspace too small");
+    const int esz = dtype == MM_BF16 ? 2 : 4;
+    MM_CHECK(dtype == MM_BF16 || dtype == MM_F32, "relu2_bwd_colsum: bad dtype %d", dtype);
+    MM_CHECK((N % (16 / esz)) == 0 && ((((uintptr_t)h) | ((uintptr_t)da) | ((uintptr_t)dh)) % 16) == 0,
+             "relu2_bwd_colsum: needs 16-byte aligned rows (N=%lld)", (long long)N);
+    const int chunks = colsum_chunks(M);
+    const int rpc = (int)cdiv(M, chunks);
+    const int nchunks = (int)cdiv(M, rpc);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MM_F32)
+        hipLaunchKernelGGL((relu2_bwd_colsum_k<float, 4>), dim3((unsigned)cdiv(N, 128), (unsigned)nchunks), dim3(256), 0, st,
+                           (const float*)h, (const float*)da, (float*)dh, (float*)workspace, (int)M, (int)N, rpc);
+    else
+        hipLaunchKernelGGL((relu2_bwd_colsum_k<bf16, 8>), dim3((unsigned)cdiv(N, 256), (unsigned)nchunks), dim3(256), 0, st,
+                           (const bf16*)h, (const bf16*)da, (bf16*)dh, (float*)workspace, (int)M, (int)N, rpc);
+    MM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_stage2_k, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, (const float*)workspace, colsum, nchunks, (int)N);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}

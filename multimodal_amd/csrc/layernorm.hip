@@ -158,7 +158,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* __restrict__ x, 
 // Wide rows (C > 512): one BLOCK walks rows, R at a time; a thread owns VEC*CH fixed channels, so the dw/db partials
 // need no cross-thread step.  The 3*R*CH 16-byte loads of a pass are issued together and stay packed in registers
 // (bf16 rows: 4 VGPRs per load) until used; each row is unpacked once for the sums and once for dx.
-template <typename T, int VEC, int CH, int R>
+// SUMS: also accumulate the column sums of the residual-gradient input (dres) and of the produced dx -- the bias gradients of
+// the two linears on either side of the LayerNorm in a pre-LN residual block -- as partial kinds 2 and 3.
+template <typename T, int VEC, int CH, int R, bool SUMS>
 __global__ __launch_bounds__(256) void layernorm_bwd_blk_k(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const T* __restrict__ dres, const float* __restrict__ w,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -167,12 +169,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_blk_k(const T* __restrict__
     typedef typename VecIO<T, VEC>::raw_t raw_t;
     __shared__ float red[2][R][2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float pw[CH][VEC], pb[CH][VEC], wv[CH][VEC];
+    constexpr int NK = SUMS ? 4 : 2;
+    float pw[CH][VEC], pb[CH][VEC], wv[CH][VEC], pr[SUMS ? CH : 1][VEC], px[SUMS ? CH : 1][VEC];
 #pragma unroll
     for (int k = 0; k < CH; k++) {
         const int c = (k * 256 + tid) * VEC;
 #pragma unroll
-        for (int i = 0; i < VEC; i++) { pw[k][i] = 0.f; pb[k][i] = 0.f; wv[k][i] = (c + i < C) ? w[c + i] : 0.f; }
+        for (int i = 0; i < VEC; i++) {
+            pw[k][i] = 0.f; pb[k][i] = 0.f; wv[k][i] = (c + i < C) ? w[c + i] : 0.f;
+            if (SUMS) { pr[k][i] = 0.f; px[k][i] = 0.f; }
+        }
     }
     const float invC = 1.0f / (float)C;
     int par = 0;
@@ -236,7 +242,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_blk_k(const T* __restrict__
 #pragma unroll
                         for (int i = 0; i < VEC; i++) {
                             const float h = (xv[i] - mu[r]) * rs[r];
+                            if (SUMS) pr[k][i] += o[i];
                             o[i] += rs[r] * (gy[i] * wv[k][i] - m1 - h * m2);
+                            if (SUMS) px[k][i] += o[i];
                         }
                         VecIO<T, VEC>::store(dx + row * C + c, o);
                     }
@@ -250,8 +258,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_blk_k(const T* __restrict__
 #pragma unroll
         for (int i = 0; i < VEC; i++)
             if (c + i < C) {
-                partial[((long)blockIdx.x * 2 + 0) * C + c + i] = pw[k][i];
-                partial[((long)blockIdx.x * 2 + 1) * C + c + i] = pb[k][i];
+                partial[((long)blockIdx.x * NK + 0) * C + c + i] = pw[k][i];
+                partial[((long)blockIdx.x * NK + 1) * C + c + i] = pb[k][i];
+                if (SUMS) {
+                    partial[((long)blockIdx.x * NK + 2) * C + c + i] = pr[k][i];
+                    partial[((long)blockIdx.x * NK + 3) * C + c + i] = px[k][i];
+                }
             }
     }
 }
@@ -259,7 +271,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_blk_k(const T* __restrict__
 // out0[c] = sum_r partial[r][c], out1[c] = sum_r partial[r][C + c]  (width = 2*C); a block covers 16 columns with
 // 16 row groups (64-byte coalesced reads, 8 loads in flight per thread), fixed summation order.
 __global__ __launch_bounds__(256) void rows_reduce_k(const float* __restrict__ partial, int nrows, int width,
-                                                     float* __restrict__ out0, float* __restrict__ out1, int C) {
+                                                     float* __restrict__ out0, float* __restrict__ out1, int C,
+                                                     float* __restrict__ out2 = nullptr, float* __restrict__ out3 = nullptr) {
     __shared__ float red[16][17];
     const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int idx = blockIdx.x * 16 + cl;
@@ -281,7 +294,8 @@ __global__ __launch_bounds__(256) void rows_reduce_k(const float* __restrict__ p
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; k++) t += red[k][cl];
-        if (idx < C) out0[idx] = t; else out1[idx - C] = t;
+        if (idx < C) out0[idx] = t; else if (idx < 2 * C) out1[idx - C] = t;
+        else if (idx < 3 * C) out2[idx - 2 * C] = t; else out3[idx - 3 * C] = t;
     }
 }
 
@@ -328,18 +342,19 @@ static int64_t ln_bwd_blocks(int64_t rows, int64_t C) {
 }
 extern "C" size_t mm_layernorm_bwd_workspace(int64_t rows, int64_t C) {
     if (rows <= 0 || C <= 0) return 0;
-    return (size_t)ln_bwd_blocks(rows, C) * 2 * (size_t)C * sizeof(float);
+    return (size_t)ln_bwd_blocks(rows, C) * 4 * (size_t)C * sizeof(float);      // 4: room for the two optional column sums
 }
 
 template <typename T>
 static int ln_bwd_launch(const void* x, const void* dy, const void* dres, const float* w, const float* mean,
                          const float* rstd, void* dx, float* partial, int64_t nb, int64_t G, int64_t Lin, int64_t Lout,
-                         int64_t C, hipStream_t st) {
+                         int64_t C, hipStream_t st, bool sums = false) {
     const long rows_in = G * Lin;
 #define L_(VEC_, CH_) hipLaunchKernelGGL((layernorm_bwd_k<T, VEC_, CH_>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, \
                                          (const T*)dy, (const T*)dres, w, mean, rstd, (T*)dx, partial, rows_in, (int)Lin, (int)Lout, (int)C)
-#define W_(VEC_, CH_) hipLaunchKernelGGL((layernorm_bwd_blk_k<T, VEC_, CH_, LN_BWD_R>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, \
+#define W1_(VEC_, CH_, S_) hipLaunchKernelGGL((layernorm_bwd_blk_k<T, VEC_, CH_, LN_BWD_R, S_>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, \
                                          (const T*)dy, (const T*)dres, w, mean, rstd, (T*)dx, partial, rows_in, (int)Lin, (int)Lout, (int)C)
+#define W_(VEC_, CH_) do { if (sums) W1_(VEC_, CH_, true); else W1_(VEC_, CH_, false); } while (0)
     if (ln_bwd_wide(C)) {
         bool done = false;
         if constexpr (sizeof(T) == 2) {
@@ -361,6 +376,7 @@ static int ln_bwd_launch(const void* x, const void* dy, const void* dres, const 
     }
 #undef L_
 #undef W_
+#undef W1_
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
@@ -381,7 +397,30 @@ extern "C" int mm_layernorm_bwd(const void* x, const void* dy, const void* dres,
     else MM_FAIL(MM_ERR_ARG, "layernorm_bwd: bad dtype %d", dtype);
     if (rc != MM_OK) return rc;
     hipLaunchKernelGGL(rows_reduce_k, dim3((unsigned)cdiv(2 * C, 16)), dim3(256), 0, st, (const float*)workspace, (int)nb, (int)(2 * C), dw,
-                       db, (int)C);
+                       db, (int)C, (float*)nullptr, (float*)nullptr);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
+// The same, for a pre-LN residual block  y = x + f(LN(x)):  dx = dres + LN'(dy), and additionally
+//   dres_sum[c] = sum_rows dres[row][c]   (bias gradient of the linear that produced the block's output gradient path)
+//   dx_sum[c]   = sum_rows dx[row][c]     (bias gradient of the linear that produced x)
+// so the two bias gradients cost no pass of their own.  Wide rows only (C > 512, C % 4 == 0, Lin == Lout).
+extern "C" int mm_layernorm_bwd_sums(const void* x, const void* dy, const void* dres, const float* w, const float* mean,
+                                     const float* rstd, void* dx, float* dw, float* db, float* dres_sum, float* dx_sum,
+                                     void* workspace, size_t workspace_bytes, int64_t rows, int64_t C, int dtype, void* stream) {
+    MM_CHECK(x && dy && dres && w && mean && rstd && dx && dw && db && dres_sum && dx_sum && workspace, "layernorm_bwd_sums: null pointer");
+    MM_CHECK(rows > 0 && ln_bwd_wide(C), "layernorm_bwd_sums: needs rows > 0, C > 512, C %% 4 == 0 (C=%lld)", (long long)C);
+    MM_CHECK(workspace_bytes >= mm_layernorm_bwd_workspace(rows, C), "layernorm_bwd_sums: workspace too small");
+    const int64_t nb = ln_bwd_blocks(rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (dtype == MM_F32) rc = ln_bwd_launch<float>(x, dy, dres, w, mean, rstd, dx, (float*)workspace, nb, 1, rows, rows, C, st, true);
+    else if (dtype == MM_BF16) rc = ln_bwd_launch<bf16>(x, dy, dres, w, mean, rstd, dx, (float*)workspace, nb, 1, rows, rows, C, st, true);
+    else MM_FAIL(MM_ERR_ARG, "layernorm_bwd_sums: bad dtype %d", dtype);
+    if (rc != MM_OK) return rc;
+    hipLaunchKernelGGL(rows_reduce_k, dim3((unsigned)cdiv(4 * C, 16)), dim3(256), 0, st, (const float*)workspace, (int)nb, (int)(4 * C), dw,
+                       db, (int)C, dres_sum, dx_sum);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }

@@ -439,12 +439,22 @@ class DecoderLayer(torch.autograd.Function):
         dout = dout.contiguous().view(M, D)
         # ---- the dX chain (critical path)
         dh = torch.mm(dout, cached_operand((w2,), dt))
-        ops.relu2_bwd_(h, dh)
+        esz = 2 if dt == torch.bfloat16 else 4
+        if (F4 * esz) % 16 == 0:
+            _, db1 = ops.relu2_bwd_colsum_(h, dh)                 # bias gradient of ffn_w1 in the same pass
+        else:
+            ops.relu2_bwd_(h, dh)
+            db1 = None
         if dt == torch.bfloat16:         # N = d_model, K = d_ffn: NT product on the transposed operand copy
             dxf = ops.gemm(dh, cached_operand((w1,), dt, transpose=True), M, D, F4)
         else:
             dxf = torch.mm(dh, w1.detach())
-        dx1, dln2w, dln2b = ops.layernorm_bwd(x1, dxf, dout, ln2w.detach(), mean2, rstd2)      # + residual gradient
+        if ops.layernorm_bwd_sums_ok(D):
+            # + residual gradient; column sums of dout and dx1 = bias gradients of ffn_w2 and of the out projection
+            dx1, dln2w, dln2b, db2, dbo = ops.layernorm_bwd_sums(x1, dxf, dout, ln2w.detach(), mean2, rstd2)
+        else:
+            dx1, dln2w, dln2b = ops.layernorm_bwd(x1, dxf, dout, ln2w.detach(), mean2, rstd2)  # + residual gradient
+            db2 = dbo = None
         d_o = torch.mm(dx1, cached_operand((ow,), dt)).view(B, S, D)
         dqkv = ops.prefix_attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, d_o, lse, H, 0, prompt_len, cos_t, sin_t,
                                    stablemax)                                               # saved q,k are rotated
@@ -456,12 +466,15 @@ class DecoderLayer(torch.autograd.Function):
         dxa = torch.mm(dqkv2, cached_operand((qw, kw, vw), dt))
 
         # ---- parameter gradients (off the critical path)
-        def param_grads(tag):
-            db2 = ops.colsum(dout, M, D, tag)
+        def param_grads(tag, db1=db1, db2=db2, dbo=dbo):
+            if db2 is None:
+                db2 = ops.colsum(dout, M, D, tag)
             dw2 = _weight_grad(w2, dout, a)
-            db1 = ops.colsum(dh, M, F4, tag)
+            if db1 is None:
+                db1 = ops.colsum(dh, M, F4, tag)
             dw1 = _weight_grad(w1, dh, xf)
-            dbo = ops.colsum(dx1, M, D, tag)
+            if dbo is None:
+                dbo = ops.colsum(dx1, M, D, tag)
             dwo = _weight_grad(ow, dx1, o.view(M, D))
             dbqkv = ops.colsum(dqkv2, M, 3 * D, tag)
             dqw, dkw, dvw = _stacked_weight_grads((qw, kw, vw), dqkv2, xa2)

@@ -163,6 +163,25 @@ def layernorm_bwd(x: Tensor, dy: Tensor, dres: Optional[Tensor], w: Tensor, mean
     return dx, dw, db
 
 
+def layernorm_bwd_sums_ok(Cc: int) -> bool:
+    return Cc > 512 and Cc % 4 == 0
+
+
+def layernorm_bwd_sums(x: Tensor, dy: Tensor, dres: Tensor, w: Tensor, mean: Tensor, rstd: Tensor):
+    """layernorm_bwd with a residual gradient, plus the column sums of dres and of dx (two bias gradients for free)."""
+    _chk(x, "x"); _chk(dy, "dy", x.dtype); _chk(dres, "dres", x.dtype)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    dx = torch.empty_like(x)
+    out = torch.empty((4, Cc), dtype=torch.float32, device=x.device)
+    nbytes = L.lib().mm_layernorm_bwd_workspace(rows, Cc)
+    ws = workspace(nbytes, x.device)
+    L.check(L.lib().mm_layernorm_bwd_sums(L.ptr(x), L.ptr(dy), L.ptr(dres), L.ptr(w), L.ptr(mean), L.ptr(rstd), L.ptr(dx),
+                                          L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(out[3]), L.ptr(ws), nbytes, rows, Cc,
+                                          L.dtype_code(x), L.cur_stream()), "mm_layernorm_bwd_sums")
+    return dx, out[0], out[1], out[2], out[3]
+
+
 # --------------------------------------------------------------------------- GEMM
 ACT_NONE, ACT_GELU, ACT_RELU2 = 0, 1, 2
 
@@ -344,6 +363,20 @@ def relu2_bwd_(h: Tensor, da: Tensor) -> Tensor:
         raise RuntimeError("relu2_bwd: shape mismatch")
     L.check(L.lib().mm_relu2_bwd(L.ptr(h), L.ptr(da), L.ptr(da), h.numel(), L.dtype_code(h), L.cur_stream()), "mm_relu2_bwd")
     return da
+
+
+def relu2_bwd_colsum_(h: Tensor, da: Tensor):
+    """da <- da * 2*relu(h) in place over [M, N]; also returns the column sums of the result (the bias gradient)."""
+    _chk(h, "h"); _chk(da, "da", h.dtype)
+    if da.shape != h.shape or h.dim() != 2:
+        raise RuntimeError("relu2_bwd_colsum: expected two [M, N] tensors")
+    M, N = h.shape
+    out = torch.empty(N, dtype=torch.float32, device=h.device)
+    nbytes = L.lib().mm_colsum_workspace(M, N)
+    ws = workspace(nbytes, h.device)
+    L.check(L.lib().mm_relu2_bwd_colsum(L.ptr(h), L.ptr(da), L.ptr(da), L.ptr(out), L.ptr(ws), nbytes, M, N, L.dtype_code(h),
+                                        L.cur_stream()), "mm_relu2_bwd_colsum")
+    return da, out
 
 
 def cast_transpose(w: Tensor, out: Tensor) -> Tensor:

@@ -150,6 +150,46 @@ def test_layernorm(G, Lin, Lout, C, dtype):
     assert rel_err(db.cpu(), b.grad) < ptol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(315, 1600), (2600, 768), (7, 2048), (1, 516), (530, 4096)])
+def test_layernorm_bwd_with_bias_gradient_sums(rows, C, dtype):
+    """mm_layernorm_bwd_sums == mm_layernorm_bwd + the column sums of its residual input and of its dx output."""
+    from multimodal_amd import ops
+    d = _dev()
+    x = _rand(rows, C, seed=1).to(dtype).to(d)
+    w = (1 + _rand(C, seed=2, scale=0.2)).to(d)
+    b = _rand(C, seed=3, scale=0.1).to(d)
+    _, mean, rstd = ops.layernorm_fwd(x, w, b, save_stats=True)
+    dy = _rand(rows, C, seed=4).to(dtype).to(d)
+    dres = _rand(rows, C, seed=5).to(dtype).to(d)
+    dx0, dw0, db0 = ops.layernorm_bwd(x, dy, dres, w, mean, rstd)
+    dx1, dw1, db1, rsum, xsum = ops.layernorm_bwd_sums(x, dy, dres, w, mean, rstd)
+    assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    assert rel_err(rsum.cpu(), dres.float().sum(0).cpu()) < 1e-5
+    # the kernel sums dx before it is rounded to the storage dtype
+    assert rel_err(xsum.cpu(), dx0.float().sum(0).cpu()) < (1e-5 if dtype == torch.float32 else 5e-3)
+    assert not ops.layernorm_bwd_sums_ok(512) and not ops.layernorm_bwd_sums_ok(1030)
+    with pytest.raises(RuntimeError):
+        ops.layernorm_bwd_sums(x[:, :256].contiguous(), dy[:, :256].contiguous(), dres[:, :256].contiguous(), w[:256],
+                               mean, rstd)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N", [(315, 6400), (1234, 776), (3, 8), (10080, 256)])
+def test_relu2_bwd_with_bias_gradient_sum(M, N, dtype):
+    from multimodal_amd import ops
+    d = _dev()
+    h = _rand(M, N, seed=2, scale=2.0).to(dtype).to(d)
+    da = _rand(M, N, seed=3).to(dtype).to(d)
+    ref = ops.relu2_bwd_(h, da.clone())
+    got, s = ops.relu2_bwd_colsum_(h, da.clone())
+    assert torch.equal(got, ref)
+    assert rel_err(s.cpu(), ref.float().sum(0).cpu()) < 1e-5
+    if dtype == torch.bfloat16:
+        with pytest.raises(RuntimeError):
+            ops.relu2_bwd_colsum_(h[:, :4].contiguous(), da[:, :4].contiguous())      # rows not 16-byte multiples
+
+
 GEMM_SHAPES = [(992, 6400, 1600), (8000, 256, 64), (100, 591, 768), (77, 130, 250), (16, 16, 8), (1, 1, 1),
                (300, 200, 200), (513, 129, 1030), (1984, 512, 128)]
 
