@@ -74,3 +74,23 @@ def formula_state_dict(cfg: Cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
     for i in range(cfg.num_layers):
         sd[f"decoder.layers.{i}.rotary_emb.inv_freq"] = inv.clone()
     return sd
+
+
+def decoder_state_shapes(cfg: Cfg, memory_dim: int) -> Dict[str, Tuple[int, ...]]:
+    """Keys of a stand-alone SMILESDecoder (no 'decoder.' prefix); memory_proj is a Linear when memory_dim differs from
+    embed_dim (models/transformer_decoder.py:199)."""
+    s = {k[len("decoder."):]: v for k, v in state_shapes(cfg).items() if k.startswith("decoder.")}
+    if memory_dim != cfg.embed_dim:
+        s["memory_proj.weight"] = (cfg.embed_dim, memory_dim)
+        s["memory_proj.bias"] = (cfg.embed_dim,)
+    return s
+
+
+def decoder_formula_state_dict(cfg: Cfg, memory_dim: int, seed: int = 0) -> Dict[str, torch.Tensor]:
+    from . import fill
+    sd = fill.make_state_dict(decoder_state_shapes(cfg, memory_dim), seed)
+    rot = int((cfg.embed_dim // cfg.num_heads) * 0.5)
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2).float() / rot))
+    for i in range(cfg.num_layers):
+        sd[f"layers.{i}.rotary_emb.inv_freq"] = inv.clone()
+    return sd

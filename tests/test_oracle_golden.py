@@ -140,3 +140,55 @@ def test_orthograd_adamw_restatement_matches_reference(name):
         opt.step()
         for i, p in enumerate(ps):
             assert torch.equal(p.detach(), torch.from_numpy(gold[f"{name}.step{t}.p{i}"])), (t, i)
+
+
+def _edge_sd(c, module_keys_prefix="full"):
+    from oracle.restate import Cfg
+    cfg = Cfg(embed_dim=c["E"], num_heads=c["H"], num_layers=c["L"], max_seq_length=c["max_seq"],
+              max_nmr_length=c["max_nmr"], max_memory_length=c["max_mem"], use_stablemax=c["sm"])
+    return cfg, formula_state_dict(cfg)
+
+
+@pytest.mark.parametrize("name", ["no_nmr", "truncate", "b1t1", "padded"])
+def test_edge_cases_match_reference(name):
+    """nmr_tokens=None, both truncation rules, B=1/T=1, [PAD]-ragged targets (tests/golden/edge.npz, produced by the
+    reference through oracle/gen_golden_edge.py)."""
+    import numpy as np
+    from oracle.gen_golden_edge import EDGE, PAD_GRAD_KEYS, edge_inputs, padded_targets
+    gold = np.load(os.path.join(GOLDEN, "edge.npz"), allow_pickle=False)
+    c = EDGE[name]
+    cfg, sd = _edge_sd(c)
+    ir, nmr, tgt = edge_inputs(c)
+    if name != "padded":
+        with torch.no_grad():
+            lg = restate.model_forward(sd, cfg, nmr, ir, tgt[:, :-1])
+        assert rel_err(lg, gold[name + ".logits"]) < 2e-5
+        return
+    tgt = padded_targets(c)
+    for k in sd:
+        sd[k].requires_grad_(sd[k].is_floating_point())
+    loss = restate.train_loss(sd, cfg, nmr, ir, tgt, training=False)
+    loss.backward()
+    assert abs(loss.item() - float(gold["padded.loss"])) < 1e-5 * abs(float(gold["padded.loss"]))
+    for k in PAD_GRAD_KEYS:
+        assert rel_err(sd[k].grad, gold["padded.grad." + k]) < 1e-4, k
+    assert rel_err(sd["decoder.smiles_embed.weight"].grad, gold["padded.grad.smiles_embed"]) < 1e-4
+
+
+def test_memory_projection_and_length_guard_match_reference():
+    import numpy as np
+    from oracle.gen_golden_edge import MEMPROJ, memproj_inputs
+    from oracle.shapes import decoder_formula_state_dict
+    from oracle.restate import Cfg
+    gold = np.load(os.path.join(GOLDEN, "edge.npz"), allow_pickle=False)
+    c = MEMPROJ
+    cfg = Cfg(embed_dim=c["E"], num_heads=c["H"], num_layers=c["L"], max_seq_length=c["max_seq"],
+              max_nmr_length=c["max_nmr"], max_memory_length=c["max_mem"], use_stablemax=c["sm"])
+    sd = decoder_formula_state_dict(cfg, c["memory_dim"])
+    mem, nmr, tgt = memproj_inputs()
+    with torch.no_grad():
+        lg = restate.smiles_decoder(sd, tgt, mem, nmr, cfg, pre="")
+    assert rel_err(lg, gold["memproj.logits"]) < 2e-5
+    with pytest.raises(ValueError) as ei:
+        restate.smiles_decoder(sd, torch.full((2, 95 + 256 - 31 - 4 + 1), 20), mem, nmr, cfg, pre="")
+    assert str(ei.value) == str(gold["guard.message"])
