@@ -13,7 +13,9 @@ import os
 import sys
 import time
 
-import torch
+if int(os.environ.get("RANK", "0")) == 0:       # the first import of torch on a fresh box can take minutes
+    print(f"[bench {time.strftime('%H:%M:%S')}] importing torch", file=sys.stderr, flush=True)
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -27,6 +29,12 @@ CONFIGS = {
 }
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide)
+
+
+def log(msg):
+    """Progress on stderr (stdout carries exactly one JSON line): a silent minute-long phase looks like a hang."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def build_model(c, device, seed=0):
@@ -103,6 +111,67 @@ def gemm_roofline(device, M=10080, N=1600, K=6400, iters=20):
     return {"kernel": "gemm_big_k<bf16,7,5>", "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "launch_us": round(t * 1e6, 2),
             "shape": {"M": M, "N": N, "K": K, "dtype": "bfloat16", "epilogue": "bias+residual"}}
+
+
+def _event_time(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def attn_roofline(device, B=32, H=16, d=100, N=190, T=94):
+    """K3 / K3b at the local_config shape (S = 31+N+T = 315, prompt 221, stablemax, bf16, q/k pre-rotated as in the
+    model): SURVEY 8d flops 4*B*S^2*E forward, 2.5x that backward (mask sparsity not discounted), against the dense bf16
+    MFMA peak.  The stablemax arithmetic makes these kernels VALU-bound, so the fraction is far from 1 by construction."""
+    from multimodal_amd import ops
+    E, S, P = H * d, 31 + N + T, 31 + N
+    rot = int(d * 0.5)
+    qkv = (torch.rand(B, S, 3, E, device=device) * 2 - 1).to(torch.bfloat16)
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2, device=device).float() / rot))
+    cos_t, sin_t = ops.rope_tables(inv, S)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    ops.rope_inplace(qkv.view(B, S, 3 * E)[:, :, :2 * E], 2 * H, rot, cos_t, sin_t)
+    o, lse = ops.prefix_attn_fwd(q, k, v, H, 0, P, cos_t, sin_t, True, save_lse=True)
+    do = torch.randn_like(o)
+    tf = _event_time(lambda: ops.prefix_attn_fwd(q, k, v, H, 0, P, cos_t, sin_t, True, save_lse=True))
+    tb = _event_time(lambda: ops.prefix_attn_bwd(q, k, v, o, do, lse, H, 0, P, cos_t, sin_t, True))
+    fl = 4.0 * B * S * S * E
+    af, ab = fl / tf / 1e12, 2.5 * fl / tb / 1e12
+    return {"kernel": "prefix_attn_fwd2_k / prefix_attn_bwd_dq5_k + _dkv5_k", "bound": "mfma", "unit": "TFLOP/s",
+            "peak": MFMA_BF16_PEAK_TFLOPS, "achieved": round(af, 1), "frac": round(af / MFMA_BF16_PEAK_TFLOPS, 4),
+            "launch_us": round(tf * 1e6, 1), "bwd_achieved": round(ab, 1), "bwd_frac": round(ab / MFMA_BF16_PEAK_TFLOPS, 4),
+            "bwd_launch_us": round(tb * 1e6, 1), "traffic": None,
+            "algorithmic_bytes_fwd": 4 * B * S * E * 2, "reference_intermediate_bytes_fwd": 7 * B * H * S * S * 4,
+            "shape": {"B": B, "H": H, "d": d, "S": S, "prompt": P, "dtype": "bfloat16", "stablemax": True}}
+
+
+def decode_roofline(device, B=1024, H=8, d=128, Smax=238):
+    """K4 at the nocat greedy shape, last position: algorithmic bytes = the K and V cache rows read once,
+    B*H*2*(pos+1)*d*2, against HBM."""
+    from multimodal_amd import ops
+    E = H * d
+    rot = int(d * 0.5)
+    pos = Smax - 1
+    kc = (torch.rand(B, H, Smax, d, device=device) - 0.5).to(torch.bfloat16)
+    vc = (torch.rand(B, H, Smax, d, device=device) - 0.5).to(torch.bfloat16)
+    qkv = (torch.rand(B, 3 * E, device=device) - 0.5).to(torch.bfloat16)
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2, device=device).float() / rot))
+    cos_t, sin_t = ops.rope_tables(inv, Smax)
+    t = _event_time(lambda: ops.decode_attn(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], kc, vc, H, rot, pos, cos_t, sin_t, False),
+                    iters=50)
+    nbytes = B * H * 2 * (pos + 1) * d * 2
+    ach = nbytes / t / 1e9
+    return {"kernel": "decode_attn_k", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "launch_us": round(t * 1e6, 2),
+            "algorithmic_bytes_per_launch": nbytes,
+            "shape": {"B": B, "H": H, "d": d, "pos": pos, "dtype": "bfloat16", "softmax": True}}
 
 
 def greedy_bench(device, world, rank):
@@ -245,6 +314,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    log(f"torch {torch.__version__} up, device {torch.cuda.get_device_name(local)}, world {world}")
     import multimodal_amd as mm
     from multimodal_amd.dp import DataParallel
     from multimodal_amd.optim import OrthoGradAdamW
@@ -273,11 +343,13 @@ def main():
         opt.step()
         loss_acc.add_(loss.detach())
 
+    log("model built; warm-up")
     for i in range(a.warmup):
         step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    log(f"timing {a.steps} steps")
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
@@ -290,6 +362,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     final_loss = float(loss_acc.item()) / max(1, a.steps + a.warmup)
+    log(f"train leg: {elapsed / a.steps * 1e3:.2f} ms/step")
 
     extras = {}
     if not a.no_extras:
@@ -298,6 +371,7 @@ def main():
         torch.cuda.empty_cache()
         roof = k1_roofline(device)
         roof_bf16 = k1_roofline(device, torch.bfloat16)
+        log("K1 roofline done; greedy leg")
         greedy = greedy_bench(device, world, rank)
         if world > 1:
             gt = torch.tensor([greedy["tokens_per_s_per_gpu"]], device=device, dtype=torch.float64)
@@ -305,14 +379,19 @@ def main():
             greedy["tokens_per_s"] = round(float(gt.item()), 1)
         else:
             greedy["tokens_per_s"] = greedy["tokens_per_s_per_gpu"]
-        extras = {"roofline": roof, "roofline_bf16": roof_bf16, "roofline_mfma": gemm_roofline(device), "greedy": greedy}
+        extras = {"roofline": roof, "roofline_bf16": roof_bf16, "roofline_mfma": gemm_roofline(device),
+                  "roofline_attn": attn_roofline(device), "roofline_decode": decode_roofline(device), "greedy": greedy}
         extras["roofline"]["config_batch_latency_us"] = k1_roofline(device, torch.float32, B=32, iters=50)["launch_us"]
+        log("kernel rooflines done")
         if world == 1:
             extras["greedy_vs_recompute"] = greedy_nocache(device)
+            log("greedy recompute leg done; batch-256 and fp32 train legs")
             extras["train_batch256_bf16"] = train_leg(c, device, 256, torch.bfloat16, steps=4, warmup=2)
             extras["train_batch32_fp32"] = train_leg(c, device, 32, torch.float32, steps=5, warmup=2)
         if rank == 0 and world == 1:
+            log("CPU baseline (oracle, one train step on the host cores)")
             extras["cpu_baseline"] = cpu_baseline(c)
+            log("CPU baseline done")
 
     if rank == 0:
         gb = a.batch * world

@@ -91,10 +91,18 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_TRACE = bool(os.environ.get("MM_TRACE_OPS"))
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().mm_last_error()
         raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+    if _TRACE:                    # debugging aid: name every launch and wait for it, so a hung kernel is the last line
+        import sys
+        print(f"[mm] {what} ...", end="", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        print(" done", file=sys.stderr, flush=True)
 
 
 def dtype_code(t: torch.Tensor) -> int:

@@ -4,6 +4,7 @@ inside the encoder.  Compute dtype: float32 (parity mode) or bfloat16 (throughpu
 always stay float32 masters and are cast per call when the compute dtype is bfloat16."""
 from __future__ import annotations
 
+import os
 import weakref
 from contextlib import contextmanager
 from typing import Optional
@@ -394,6 +395,14 @@ def _stacked_weight_grads(params, dy2: Tensor, x2: Tensor):
     return [_weight_grad(p, dy2[:, i * r: (i + 1) * r], x2) for i, p in enumerate(params)]
 
 
+# The library GEMMs are stream-K kernels (workgroups of one launch wait for each other's partial tiles).  Two of them
+# issued from two streams share the CUs; at the config batch (B*S = 10080 rows) that has run clean over >1e5 concurrent
+# launches, but at B*S = 80640 (batch 256) the pair deadlocks reproducibly -- neither launch gets all the workgroups it
+# waits for resident.  Side-stream weight gradients are therefore limited to the row range that was validated; above it
+# they run on the main stream (at such sizes there are no idle tails left to fill anyway).
+DEFER_MAX_ROWS = int(os.environ.get("MM_DEFER_MAX_ROWS", "16384"))
+
+
 class DecoderLayer(torch.autograd.Function):
     """DecoderPromptLayer.forward (reference models/transformer_decoder.py:115-166) as one node:
          xa = LN1(x); qkv = xa Wqkv^T + b; RoPE(q,k) in place; o = K3(q,k,v); x1 = x + o Wo^T + bo
@@ -480,7 +489,7 @@ class DecoderLayer(torch.autograd.Function):
             dqw, dkw, dvw = _stacked_weight_grads((qw, kw, vw), dqkv2, xa2)
             return db2, dw2, db1, dw1, dbo, dwo, dbqkv, dqw, dkw, dvw
 
-        if defer_dw:
+        if defer_dw and M <= DEFER_MAX_ROWS:
             global _join_queued
             main, side = enter_side(x.device)
             with torch.cuda.stream(side):
