@@ -168,8 +168,13 @@ def decode_roofline(device, B=1024, H=8, d=128, Smax=238):
                     iters=50)
     nbytes = B * H * 2 * (pos + 1) * d * 2
     ach = nbytes / t / 1e9
+    traffic = None              # PMC passes over benchmarks/decode_pmc.py (same shape), summarised by benchmarks/pmc_summary.py
+    pmc = os.path.join(ROOT, "profiles", "r01_k4_pmc.json")
+    if (B, H, d, Smax) == (1024, 8, 128, 238) and os.path.exists(pmc):
+        with open(pmc) as fh:
+            traffic = int(json.load(fh)["traffic_bytes_per_launch"])
     return {"kernel": "decode_attn_k", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "launch_us": round(t * 1e6, 2),
+            "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "launch_us": round(t * 1e6, 2),
             "algorithmic_bytes_per_launch": nbytes,
             "shape": {"B": B, "H": H, "d": d, "pos": pos, "dtype": "bfloat16", "softmax": True}}
 
