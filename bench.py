@@ -231,6 +231,49 @@ def train_leg(c, device, batch, dtype, steps, warmup, rank=0):
             "dtype": str(dtype).replace("torch.", ""), "steps": steps}
 
 
+def graph_leg(device, name="local_config_nocat", batch=32, steps=20):
+    """The same train step issued eagerly and replayed from ONE captured HIP graph (multimodal_amd.graph), on a config whose
+    step is launch-bound at the config batch (the headline config is GPU-bound: its replay gains nothing)."""
+    import multimodal_amd as mm
+    from multimodal_amd.dp import DataParallel
+    from multimodal_amd.graph import CapturedTrainStep
+    from multimodal_amd.optim import OrthoGradAdamW
+    c = CONFIGS[name]
+    with mm.compute_dtype(torch.bfloat16):
+        model = build_model(c, device).train()
+        dp = DataParallel(model)
+        opt = OrthoGradAdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, ortho=True,
+                             ortho_eps=1e-8, rescale=True, capturable=True)
+        ir, nmr, tgt = synth_batch(c, batch, device, 4242)
+        crit = torch.nn.CrossEntropyLoss(ignore_index=0)
+
+        def step():
+            dp.zero_grad()
+            logits = model(nmr, ir, tgt[:, :-1], None)
+            loss = crit(logits.reshape(-1, logits.size(-1)), tgt[:, 1:].reshape(-1))
+            loss.backward()
+            dp.finish()
+            opt.step()
+            return loss.detach()
+
+        def clock(fn):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3
+        for _ in range(3):
+            step()
+        eager = clock(step)
+        cap = CapturedTrainStep(step, opt, warmup=1)
+        replay = clock(cap)
+    del model, dp, opt, cap
+    torch.cuda.empty_cache()
+    return {"config": name, "per_gpu_batch": batch, "dtype": "bfloat16", "eager_ms_per_step": round(eager, 3),
+            "graph_replay_ms_per_step": round(replay, 3), "spectra_per_s_replay": round(batch / replay * 1e3, 1), "steps": steps}
+
+
 def greedy_nocache(device, B=128):
     """The reference's decode loop (train_autoregressive.py:97-101: the whole decoder is re-run on the growing sequence
     every step) on the same device and kernels, beside the KV-cached generate, same batch: the speed-up of row K4."""
@@ -393,6 +436,8 @@ def main():
             log("greedy recompute leg done; batch-256 and fp32 train legs")
             extras["train_batch256_bf16"] = train_leg(c, device, 256, torch.bfloat16, steps=4, warmup=2)
             extras["train_batch32_fp32"] = train_leg(c, device, 32, torch.float32, steps=5, warmup=2)
+            log("captured-step leg")
+            extras["hip_graph_step"] = graph_leg(device)
         if rank == 0 and world == 1:
             log("CPU baseline (oracle, one train step on the host cores)")
             extras["cpu_baseline"] = cpu_baseline(c)

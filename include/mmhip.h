@@ -197,6 +197,14 @@ int mm_orthograd_adamw(const mm_param_desc* descs, const int32_t* chunk_tensor, 
                        const int32_t* tensor_chunk_start, int64_t n_tensors, int64_t n_chunks, int64_t chunk_elems,
                        float lr, float beta1, float beta2, float adam_eps, float weight_decay, int64_t step,
                        float ortho_eps, int rescale, int do_ortho, void* workspace, size_t workspace_bytes, void* stream);
+/* The same update with the step-dependent scalars in DEVICE memory: hyper = {lr, 1 - beta1^step, sqrt(1 - beta2^step)}.
+ * For callers that replay a captured HIP graph of the train step: the host rewrites the three floats before each replay
+ * (multimodal_amd.optim.OrthoGradAdamW(capturable=True), multimodal_amd.graph.CapturedTrainStep). */
+int mm_orthograd_adamw_dev(const mm_param_desc* descs, const int32_t* chunk_tensor, const int64_t* chunk_off,
+                           const int32_t* tensor_chunk_start, int64_t n_tensors, int64_t n_chunks, int64_t chunk_elems,
+                           const float* hyper, float beta1, float beta2, float adam_eps, float weight_decay,
+                           float ortho_eps, int rescale, int do_ortho, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 #ifdef __cplusplus
 }

@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256) void og_adamw_k(const mm_param_desc* __restric
                                                  const long* __restrict__ chunk_off, int chunk_elems, const float* __restrict__ coef,
                                                  const int* __restrict__ flag, const float* __restrict__ part2,
                                                  const int* __restrict__ tcs, float ortho_eps,
-                                                 float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s) {
+                                                 float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s,
+                                                 const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2s = hyper[2]; }      // step-dependent scalars from device memory (HIP graphs)
     const int t = chunk_tensor[blockIdx.x];
     const mm_param_desc d = descs[t];
     const long off = chunk_off[blockIdx.x];
@@ -245,13 +247,13 @@ __global__ __launch_bounds__(256) void og_adamw_k(const mm_param_desc* __restric
 extern "C" size_t mm_orthograd_adamw_workspace(int64_t n_tensors, int64_t n_chunks) {
     return (n_tensors > 0 && n_chunks > 0) ? (size_t)(4 * n_chunks + 4 * n_tensors) * sizeof(float) : 0;
 }
-extern "C" int mm_orthograd_adamw(const mm_param_desc* descs, const int32_t* chunk_tensor, const int64_t* chunk_off,
-                                  const int32_t* tensor_chunk_start, int64_t n_tensors, int64_t n_chunks, int64_t chunk_elems,
-                                  float lr, float beta1, float beta2, float adam_eps, float weight_decay, int64_t step,
-                                  float ortho_eps, int rescale, int do_ortho, void* workspace, size_t workspace_bytes,
-                                  void* stream) {
+static int og_launch(const mm_param_desc* descs, const int32_t* chunk_tensor, const int64_t* chunk_off,
+                     const int32_t* tensor_chunk_start, int64_t n_tensors, int64_t n_chunks, int64_t chunk_elems,
+                     float lr, float beta1, float beta2, float adam_eps, float weight_decay, float bc1, float bc2s,
+                     const float* hyper, float ortho_eps, int rescale, int do_ortho, void* workspace, size_t workspace_bytes,
+                     void* stream) {
     MM_CHECK(descs && chunk_tensor && chunk_off && tensor_chunk_start && workspace, "orthograd_adamw: null pointer");
-    MM_CHECK(n_tensors > 0 && n_chunks > 0 && chunk_elems > 0 && step >= 1, "orthograd_adamw: bad sizes/step");
+    MM_CHECK(n_tensors > 0 && n_chunks > 0 && chunk_elems > 0, "orthograd_adamw: bad sizes");
     MM_CHECK(workspace_bytes >= mm_orthograd_adamw_workspace(n_tensors, n_chunks), "orthograd_adamw: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
@@ -269,12 +271,33 @@ extern "C" int mm_orthograd_adamw(const mm_param_desc* descs, const int32_t* chu
             MM_LAUNCH_CHECK();
         }
     }
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(og_adamw_k, dim3((unsigned)n_chunks), dim3(256), 0, st, descs, (const int*)chunk_tensor, (const long*)chunk_off, (int)chunk_elems,
-                       do_ortho ? coef : nullptr, (const int*)flag, (const float*)part2, (const int*)tensor_chunk_start, ortho_eps, lr, beta1, beta2, adam_eps, weight_decay, bc1, bc2s);
+                       do_ortho ? coef : nullptr, (const int*)flag, (const float*)part2, (const int*)tensor_chunk_start, ortho_eps, lr, beta1, beta2, adam_eps, weight_decay, bc1, bc2s, hyper);
     MM_LAUNCH_CHECK();
     return MM_OK;
+}
+extern "C" int mm_orthograd_adamw(const mm_param_desc* descs, const int32_t* chunk_tensor, const int64_t* chunk_off,
+                                  const int32_t* tensor_chunk_start, int64_t n_tensors, int64_t n_chunks, int64_t chunk_elems,
+                                  float lr, float beta1, float beta2, float adam_eps, float weight_decay, int64_t step,
+                                  float ortho_eps, int rescale, int do_ortho, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    MM_CHECK(step >= 1, "orthograd_adamw: step must be >= 1");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    return og_launch(descs, chunk_tensor, chunk_off, tensor_chunk_start, n_tensors, n_chunks, chunk_elems, lr, beta1, beta2,
+                     adam_eps, weight_decay, bc1, bc2s, nullptr, ortho_eps, rescale, do_ortho, workspace, workspace_bytes, stream);
+}
+// The same update with the step-dependent scalars read from device memory: hyper[0] = lr, hyper[1] = 1 - beta1^step,
+// hyper[2] = sqrt(1 - beta2^step).  A HIP graph that captured this launch stays valid while the learning-rate schedule and
+// the step count move: the host rewrites the three floats before each replay.
+extern "C" int mm_orthograd_adamw_dev(const mm_param_desc* descs, const int32_t* chunk_tensor, const int64_t* chunk_off,
+                                      const int32_t* tensor_chunk_start, int64_t n_tensors, int64_t n_chunks,
+                                      int64_t chunk_elems, const float* hyper, float beta1, float beta2, float adam_eps,
+                                      float weight_decay, float ortho_eps, int rescale, int do_ortho, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    MM_CHECK(hyper, "orthograd_adamw_dev: null hyper");
+    return og_launch(descs, chunk_tensor, chunk_off, tensor_chunk_start, n_tensors, n_chunks, chunk_elems, 0.f, beta1, beta2,
+                     adam_eps, weight_decay, 1.f, 1.f, hyper, ortho_eps, rescale, do_ortho, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -22,13 +22,45 @@ class ParamDesc(C.Structure):
 
 
 class OrthoGradAdamW(torch.optim.Optimizer):
+    """capturable=True keeps the step-dependent scalars (learning rate, bias corrections) in device memory, so a HIP graph
+    that captured step() stays valid across steps: advance() (called by step() itself outside capture, by
+    graph.CapturedTrainStep before each replay) moves the step count and uploads the scalars."""
+
     def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
-                 ortho=True, ortho_eps=1e-30, rescale=True):
+                 ortho=True, ortho_eps=1e-30, rescale=True, capturable=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, ortho=ortho, ortho_eps=ortho_eps,
                         rescale=rescale)
         super().__init__(params, defaults)
         self._tables = {}
         self._step = 0
+        self.capturable = bool(capturable)
+        self._hyper = None            # [n_groups, 4] float32 on the device: lr, 1-b1^t, sqrt(1-b2^t), pad
+        self._hyper_host = None
+
+    def advance(self):
+        """Open the next step: count it and (capturable) upload lr and the bias corrections of every group."""
+        self._step += 1
+        if not self.capturable:
+            return
+        R = 8       # ring of pinned staging rows: the host may run steps ahead of the copies it has queued
+        if self._hyper is None:
+            dev = self.param_groups[0]["params"][0].device
+            self._hyper_host = torch.zeros(R, len(self.param_groups), 4, dtype=torch.float32).pin_memory()
+            self._hyper_ev = [None] * R
+            self._hyper = torch.zeros(len(self.param_groups), 4, dtype=torch.float32, device=dev)
+        slot = self._step % R
+        if self._hyper_ev[slot] is not None:
+            self._hyper_ev[slot].synchronize()      # the copy queued R steps ago has read this row
+        row = self._hyper_host[slot]
+        for gi, g in enumerate(self.param_groups):
+            b1, b2 = g["betas"]
+            row[gi, 0] = float(g["lr"])
+            row[gi, 1] = 1.0 - b1 ** self._step
+            row[gi, 2] = (1.0 - b2 ** self._step) ** 0.5
+        self._hyper.copy_(row, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hyper_ev[slot] = ev
 
     @staticmethod
     def _key(plist, shadows):
@@ -74,6 +106,16 @@ class OrthoGradAdamW(torch.optim.Optimizer):
         nbytes = L.lib().mm_orthograd_adamw_workspace(tab["n_tensors"], tab["n_chunks"])
         ws = ops.workspace(nbytes, plist[0].device, "optim")
         b1, b2 = group["betas"]
+        if self.capturable:
+            gi = next(i for i, g in enumerate(self.param_groups) if g is group)
+            L.check(L.lib().mm_orthograd_adamw_dev(L.ptr(tab["descs"]), L.ptr(tab["ct"]), L.ptr(tab["co"]), L.ptr(tab["tcs"]),
+                                                   tab["n_tensors"], tab["n_chunks"], CHUNK, self._hyper[gi].data_ptr(), b1, b2,
+                                                   group["eps"], group["weight_decay"], group["ortho_eps"],
+                                                   int(group["rescale"]), int(group["ortho"]), L.ptr(ws), nbytes,
+                                                   L.cur_stream()), "mm_orthograd_adamw_dev")
+            torch.autograd.graph.increment_version(plist)
+            FN.shadows_written([p for p, s in zip(plist, shadows) if s is not None])
+            return
         L.check(L.lib().mm_orthograd_adamw(L.ptr(tab["descs"]), L.ptr(tab["ct"]), L.ptr(tab["co"]), L.ptr(tab["tcs"]),
                                            tab["n_tensors"], tab["n_chunks"], CHUNK, group["lr"], b1, b2, group["eps"],
                                            group["weight_decay"], self._step, group["ortho_eps"], int(group["rescale"]),
@@ -85,7 +127,7 @@ class OrthoGradAdamW(torch.optim.Optimizer):
     # ---- optimizer-in-backward (driven by dp.DataParallel.attach_optimizer): OrthoGrad and AdamW are per-tensor, so a
     # bucket of parameters can be updated as soon as its gradients are final, while backward continues on other layers
     def begin_step(self):
-        self._step += 1
+        self.advance()
         self._begun = True
         self._done = set()
         self._group_of = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
@@ -111,8 +153,9 @@ class OrthoGradAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         begun = getattr(self, "_begun", False)
-        if not begun:
-            self._step += 1
+        capturing = self.capturable and torch.cuda.is_current_stream_capturing()
+        if not begun and not capturing:          # under capture the replaying caller advances (graph.CapturedTrainStep)
+            self.advance()
         done = self._done if begun else ()
         FN.join_side_stream()
         for gi, group in enumerate(self.param_groups):
