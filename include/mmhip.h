@@ -155,6 +155,11 @@ int mm_rope_inplace(void* x, const float* cos_t, const float* sin_t, int64_t B, 
 int mm_decode_attn(const void* q, const void* k_new, const void* v_new, void* kcache, void* vcache, void* o,
                    const float* cos_t, const float* sin_t, int64_t B, int64_t H, int64_t d, int64_t rot,
                    int64_t pos, int64_t Smax, int64_t ld_qkv, int mode, int dtype, void* stream);
+/* The same step with the position read from device memory (*pos_dev, clamped to [0, Smax-1]), for a decode step captured
+ * once in a HIP graph and replayed per token (multimodal_amd/generate.py). */
+int mm_decode_attn_dev(const void* q, const void* k_new, const void* v_new, void* kcache, void* vcache, void* o,
+                       const float* cos_t, const float* sin_t, int64_t B, int64_t H, int64_t d, int64_t rot,
+                       const int32_t* pos_dev, int64_t Smax, int64_t ld_qkv, int mode, int dtype, void* stream);
 /* prefill: rotate K of the prompt rows and copy K,V into the cache (same layout as above). */
 int mm_kv_cache_fill(const void* k, const void* v, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
                      int64_t B, int64_t H, int64_t S, int64_t d, int64_t rot, int64_t Smax, int64_t ld_qkv,

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "mm_prefix_attn_bwd": (i32, [vp] * 11 + [vp, sz] + [i64] * 8 + [i32, i32, vp]),
     "mm_rope_inplace": (i32, [vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i32, vp]),
     "mm_decode_attn": (i32, [vp] * 8 + [i64] * 7 + [i32, i32, vp]),
+    "mm_decode_attn_dev": (i32, [vp] * 8 + [i64] * 4 + [vp] + [i64] * 2 + [i32, i32, vp]),
     "mm_kv_cache_fill": (i32, [vp] * 6 + [i64] * 7 + [i32, vp]),
     "mm_layerscale_bwd_workspace": (sz, [i64, i64]),
     "mm_layerscale_bwd": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp, sz, i64, i64, i32, vp]),

@@ -1514,6 +1514,7 @@ struct DecP {
     const void* q; const void* kn; const void* vn; void* kc; void* vc; void* o;
     const float* cos_t; const float* sin_t;
     int B, H, d, rot, pos, Smax; long ld; float scale; int mode;
+    const int* pos_dev;          // if set: the position is read from device memory (captured HIP graphs), clamped to Smax-1
 };
 
 template <typename T, int VEC, int CH>
@@ -1526,7 +1527,7 @@ __global__ __launch_bounds__(256) void decode_attn_k(const DecP p) {
     const int bh = blockIdx.x * 4 + wave;
     if (bh >= p.B * p.H) return;                       // wave-uniform
     const int b = bh / p.H, h = bh % p.H;
-    const int d = p.d, half = p.rot >> 1, pos = p.pos;
+    const int d = p.d, half = p.rot >> 1, pos = p.pos_dev ? min(max(*p.pos_dev, 0), p.Smax - 1) : p.pos;
     const T* qg = (const T*)p.q + (long)b * p.ld + (long)h * d;
     const T* kng = (const T*)p.kn + (long)b * p.ld + (long)h * d;
     const T* vng = (const T*)p.vn + (long)b * p.ld + (long)h * d;
@@ -1691,9 +1692,9 @@ extern "C" int mm_kv_cache_fill(const void* k, const void* v, void* kcache, void
     return MM_OK;
 }
 
-extern "C" int mm_decode_attn(const void* q, const void* k_new, const void* v_new, void* kcache, void* vcache, void* o,
-                              const float* cos_t, const float* sin_t, int64_t B, int64_t H, int64_t d, int64_t rot,
-                              int64_t pos, int64_t Smax, int64_t ld_qkv, int mode, int dtype, void* stream) {
+static int decode_launch(const void* q, const void* k_new, const void* v_new, void* kcache, void* vcache, void* o,
+                         const float* cos_t, const float* sin_t, int64_t B, int64_t H, int64_t d, int64_t rot,
+                         int64_t pos, const int32_t* pos_dev, int64_t Smax, int64_t ld_qkv, int mode, int dtype, void* stream) {
     MM_CHECK(q && k_new && v_new && kcache && vcache && o, "decode_attn: null pointer");
     MM_CHECK(B > 0 && H > 0 && d > 0 && d <= 512, "decode_attn: bad shape (d=%lld, max 512)", (long long)d);
     MM_CHECK(pos >= 0 && pos < Smax && Smax <= 1024, "decode_attn: pos=%lld Smax=%lld (Smax <= 1024)", (long long)pos, (long long)Smax);
@@ -1703,7 +1704,7 @@ extern "C" int mm_decode_attn(const void* q, const void* k_new, const void* v_ne
     DecP p{};
     p.q = q; p.kn = k_new; p.vn = v_new; p.kc = kcache; p.vc = vcache; p.o = o; p.cos_t = cos_t; p.sin_t = sin_t;
     p.B = (int)B; p.H = (int)H; p.d = (int)d; p.rot = (int)rot; p.pos = (int)pos; p.Smax = (int)Smax; p.ld = ld_qkv;
-    p.scale = (float)(1.0 / sqrt((double)d)); p.mode = mode;
+    p.scale = (float)(1.0 / sqrt((double)d)); p.mode = mode; p.pos_dev = (const int*)pos_dev;
     const dim3 grid((unsigned)cdiv(B * H, 4));
     hipStream_t st = (hipStream_t)stream;
     // vector width: the cache rows are d elements apart, so VEC must divide d
@@ -1720,6 +1721,20 @@ extern "C" int mm_decode_attn(const void* q, const void* k_new, const void* v_ne
 #undef L_
     MM_LAUNCH_CHECK();
     return MM_OK;
+}
+
+extern "C" int mm_decode_attn(const void* q, const void* k_new, const void* v_new, void* kcache, void* vcache, void* o,
+                              const float* cos_t, const float* sin_t, int64_t B, int64_t H, int64_t d, int64_t rot,
+                              int64_t pos, int64_t Smax, int64_t ld_qkv, int mode, int dtype, void* stream) {
+    return decode_launch(q, k_new, v_new, kcache, vcache, o, cos_t, sin_t, B, H, d, rot, pos, nullptr, Smax, ld_qkv, mode, dtype, stream);
+}
+// The same step with the position in device memory (*pos_dev, clamped to [0, Smax-1]): one captured HIP graph of a decode
+// step can be replayed for every position while a device-side counter advances.
+extern "C" int mm_decode_attn_dev(const void* q, const void* k_new, const void* v_new, void* kcache, void* vcache, void* o,
+                                  const float* cos_t, const float* sin_t, int64_t B, int64_t H, int64_t d, int64_t rot,
+                                  const int32_t* pos_dev, int64_t Smax, int64_t ld_qkv, int mode, int dtype, void* stream) {
+    MM_CHECK(pos_dev, "decode_attn_dev: null position pointer");
+    return decode_launch(q, k_new, v_new, kcache, vcache, o, cos_t, sin_t, B, H, d, rot, 0, pos_dev, Smax, ld_qkv, mode, dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -34,7 +34,13 @@ def _layer_weights(layer, dt):
 
 @torch.no_grad()
 def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Tensor, max_len: int = 128, bos_id: int = 12,
-                    eos_id: int = 13, early_stop: bool = True, sync_every: int = 8) -> torch.Tensor:
+                    eos_id: int = 13, early_stop: bool = True, sync_every: int = 8,
+                    graph: Optional[bool] = None) -> torch.Tensor:
+    """graph=True: replay the decode step from ONE captured HIP graph (position, output column and current ids live in device
+    memory and advance inside the graph).  Same kernels, same ids as the eager loop (tested), but OFF by default: on this
+    stack (ROCm 7.2) replaying the ~45-node step costs more than issuing it -- nocat shape, 80 steps: B=1024 549k vs 643k
+    tokens/s eager, B=128 181k vs 178k -- the decode loop is not host-bound (unlike the small-config train step, where
+    graph.CapturedTrainStep pays)."""
     dec = model.decoder
     dt = FN.get_compute_dtype()
     was_training = model.training
@@ -77,11 +83,9 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
     finished = nxt == eos_id
     n_done = 1
     # ---- decode steps
-    for t in range(1, steps):
-        if early_stop and t % sync_every == 0 and bool(finished.all()):        # :113 (checked every few steps)
-            break
-        pos = P + t
-        h = emb[nxt].to(dt)                                                    # [B, E]
+    def decode_step(cur, pos):
+        """One token for every row: cur [B] ids at position pos-1 -> argmax ids at pos (pos: int, or int32 device scalar)."""
+        h = emb[cur].to(dt)                                                    # [B, E]
         for li, layer in enumerate(dec.layers):
             w = weights[li]
             cos_t, sin_t = layer.rotary_emb.half_tables(Smax)
@@ -93,10 +97,49 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
             xf, _, _ = ops.layernorm_fwd(h, layer.mlp_norm.weight, layer.mlp_norm.bias)
             h = h + F.linear(F.relu(F.linear(xf, w["w1"], w["b1"])).square(), w["w2"], w["b2"])
         xt, _, _ = ops.layernorm_fwd(h, dec.final_norm.weight, dec.final_norm.bias)
-        nxt = ops.argmax_rows(F.linear(xt, w_out, b_out).float())
-        tokens[:, t + 1] = nxt
-        finished |= nxt == eos_id
-        n_done = t + 1
+        return ops.argmax_rows(F.linear(xt, w_out, b_out).float())
+
+    use_graph = bool(graph)
+    if use_graph and steps > 2:
+        cur_s = nxt.clone()
+        pos_dev = torch.tensor([P + 1], dtype=torch.int32, device=dev)
+        col_dev = torch.tensor([2], dtype=torch.long, device=dev)
+
+        def body():
+            new = decode_step(cur_s, pos_dev)
+            tokens.index_copy_(1, col_dev, new[:, None])
+            finished.logical_or_(new == eos_id)
+            cur_s.copy_(new)
+            pos_dev.add_(1)
+            col_dev.add_(1)
+
+        cur_stream = torch.cuda.current_stream(dev)
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(cur_stream)
+        with torch.cuda.stream(warm):
+            body()                                                             # t = 1, eagerly (library warm-up before capture)
+        n_done = 2
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(warm):          # bare capture: torch.cuda.graph() would also synchronize, collect garbage
+            g.capture_begin()                  # and empty the allocator cache on every generate() call
+            try:
+                body()
+            finally:
+                g.capture_end()
+        cur_stream.wait_stream(warm)
+        for t in range(2, steps):
+            if early_stop and t % sync_every == 0 and bool(finished.all()):    # :113 (checked every few steps)
+                break
+            g.replay()
+            n_done = t + 1
+    else:
+        for t in range(1, steps):
+            if early_stop and t % sync_every == 0 and bool(finished.all()):    # :113 (checked every few steps)
+                break
+            nxt = decode_step(nxt, P + t)
+            tokens[:, t + 1] = nxt
+            finished |= nxt == eos_id
+            n_done = t + 1
     if was_training:
         model.train()
     return tokens[:, : n_done + 1]

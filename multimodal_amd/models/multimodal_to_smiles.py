@@ -24,10 +24,10 @@ class MultiModalToSMILESModel(nn.Module):
         return self.decoder(target_seq, memory, nmr_tokens)
 
     @th.no_grad()
-    def generate(self, nmr_tokens, ir_data, max_len=128, bos_id=12, eos_id=13, early_stop=True):
+    def generate(self, nmr_tokens, ir_data, max_len=128, bos_id=12, eos_id=13, early_stop=True, graph=None):
         """Greedy decode with a KV cache; returns LongTensor [B, <=max_len+1] starting with BOS.  Token ids equal the
         reference loop's (train_autoregressive.py:80-116); rows keep emitting argmax ids after their EOS, as the
         reference's `current_token` does -- cut with `multimodal_amd.generate.ids_to_strings`."""
         from ..generate import greedy_generate
         return greedy_generate(self, nmr_tokens, ir_data, max_len=max_len, bos_id=bos_id, eos_id=eos_id,
-                               early_stop=early_stop)
+                               early_stop=early_stop, graph=graph)

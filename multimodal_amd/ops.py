@@ -317,6 +317,13 @@ def decode_attn(q: Tensor, k_new: Tensor, v_new: Tensor, kcache: Tensor, vcache:
     B, E = q.shape
     d = E // H
     o = torch.empty((B, E), dtype=q.dtype, device=q.device)
+    if isinstance(pos, Tensor):            # int32 device scalar: position advanced on the device (captured decode step)
+        if pos.dtype != torch.int32 or pos.numel() != 1 or not pos.is_cuda:
+            raise RuntimeError("decode_attn: a device position must be one int32 element on the GPU")
+        L.check(L.lib().mm_decode_attn_dev(L.ptr(q), L.ptr(k_new), L.ptr(v_new), L.ptr(kcache), L.ptr(vcache), L.ptr(o),
+                                           L.ptr(cos_t), L.ptr(sin_t), B, H, d, rot, L.ptr(pos), kcache.shape[2], q.stride(0),
+                                           int(stablemax), L.dtype_code(q), L.cur_stream()), "mm_decode_attn_dev")
+        return o
     L.check(L.lib().mm_decode_attn(L.ptr(q), L.ptr(k_new), L.ptr(v_new), L.ptr(kcache), L.ptr(vcache), L.ptr(o), L.ptr(cos_t),
                                    L.ptr(sin_t), B, H, d, rot, pos, kcache.shape[2], q.stride(0), int(stablemax),
                                    L.dtype_code(q), L.cur_stream()), "mm_decode_attn")

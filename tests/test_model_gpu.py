@@ -202,6 +202,21 @@ def test_greedy_generate_ids_equal_reference(golden_meta, name):
     assert ids_to_lists(toks.cpu()) == gold["ids"]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["tiny_sm", "d128_sdpa"])
+def test_greedy_graph_replay_equals_eager_loop(golden_meta, name, dtype):
+    """The decode step replayed from one captured HIP graph (device-side position / column / current ids) returns the ids
+    of the eager loop, with and without early stop, and for a second call (a new capture) on another batch."""
+    case = golden_meta["cases"][name]
+    m = build(case, dtype)
+    for seed, early in ((5, True), (6, False)):
+        ir8 = fill.synth_ir(8, 1000, seed).to(DEV)
+        nmr8 = fill.synth_tokens(8, case["N"], 0, 1000, seed).to(DEV)
+        a = m.generate(nmr8, ir8, max_len=24, early_stop=early, graph=False)
+        b = m.generate(nmr8, ir8, max_len=24, early_stop=early, graph=True)
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
 def test_greedy_strings_equal_oracle(golden_meta):
     from multimodal_amd.generate import ids_to_strings
     from multimodal_amd.models import SmilesTokenizer
