@@ -386,7 +386,7 @@ def main():
         dp.zero_grad()
         logits = model(nmr, ir, tgt[:, :-1], None)
         loss = crit(logits.reshape(-1, logits.size(-1)), tgt[:, 1:].reshape(-1))
-        loss.backward()
+        dp.scale_loss(loss).backward()            # /world here: the summed all-reduce is the average, no division pass
         dp.finish()
         opt.step()
         loss_acc.add_(loss.detach())

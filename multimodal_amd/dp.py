@@ -99,7 +99,8 @@ class _Done:
 
 
 class DataParallel:
-    """Wraps a replicated module.  Usage per step:  dp.zero_grad(); loss.backward(); dp.finish(); optimizer.step().
+    """Wraps a replicated module.  Usage per step:  dp.zero_grad(); dp.scale_loss(loss).backward(); dp.finish();
+    optimizer.step()  (plain loss.backward() also works: finish() then divides the reduced gradients by the world size).
     Gradients are complete (all in their bucket slots, averaged over ranks) only after finish().
     host_staged: run the collectives on host copies of GPU tensors -- for backends without (reliable) device support;
     defaults to True when the process group's backend is gloo, False for nccl (= RCCL)."""
@@ -122,6 +123,7 @@ class DataParallel:
         if self.world > 1:
             self.broadcast_parameters()
         self.optimizer = None
+        self._prescaled = False
         self._hooked = False
         if self.overlap:
             self._install_hooks()
@@ -178,7 +180,8 @@ class DataParallel:
             if self.optimizer is not None:
                 if self.world > 1:
                     b["work"].wait()
-                    b["flat"].mul_(1.0 / self.world)
+                    if not self._prescaled:
+                        b["flat"].mul_(1.0 / self.world)
                     b["scaled"] = True
                 self.optimizer.step_subset(b["params"], id(b))
 
@@ -191,7 +194,14 @@ class DataParallel:
         if b["pending"] == 0:
             self._launch(b)
 
+    def scale_loss(self, loss):
+        """loss / world for this step's backward: the summed all-reduce then IS the rank average and finish() skips its
+        division pass over every gradient (one read+write of all parameters' worth of HBM per step)."""
+        self._prescaled = True
+        return loss if self.world == 1 else loss * (1.0 / self.world)
+
     def zero_grad(self):
+        self._prescaled = False
         self.buckets.zero()
         for b in self.buckets.buckets:
             b["pending"] = len(b["params"])
@@ -213,7 +223,8 @@ class DataParallel:
             for b in self.buckets.buckets:
                 if not b.get("scaled", False):
                     b["work"].wait()
-                    b["flat"].mul_(1.0 / self.world)
+                    if not self._prescaled:
+                        b["flat"].mul_(1.0 / self.world)
 
     def __call__(self, *a, **kw):
         return self.module(*a, **kw)

@@ -20,7 +20,7 @@ def _data():
     return torch.randn(8, 16, generator=g), torch.randint(0, 5, (8,), generator=g)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, prescale=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -35,7 +35,8 @@ def _worker(rank, world, port, q):
     xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
     for _ in range(2):
         dp.zero_grad()
-        torch.nn.functional.cross_entropy(dp(xs), ys).backward()
+        loss = torch.nn.functional.cross_entropy(dp(xs), ys)
+        (dp.scale_loss(loss) if prescale else loss).backward()
         dp.finish()
         opt.step()
     if rank == 0:
@@ -44,11 +45,16 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_rank_on_concatenated_batch():
+import pytest
+
+
+@pytest.mark.parametrize("prescale", [False, True])
+def test_two_rank_step_equals_single_rank_on_concatenated_batch(prescale):
+    """prescale: dp.scale_loss() divides the loss by the world size, finish() then skips its division pass."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 1000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + os.getpid() % 1000 + (1000 if prescale else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, prescale)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)

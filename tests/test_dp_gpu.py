@@ -59,7 +59,7 @@ def _worker(rank, world, port, dtype, q):
     for _ in range(2):                              # second step: zero_grad() state reset, no stale gradients
         dp.zero_grad()
         # sum over this rank's tokens / global token count, x world: the rank average is the global-batch mean
-        _loss(m, ir[sl], nmr[sl], tgt[sl], n_tok / world).backward()
+        dp.scale_loss(_loss(m, ir[sl], nmr[sl], tgt[sl], n_tok / world)).backward()     # finish() skips its division
         launched = sum(bool(b.get("launched")) for b in dp.buckets.buckets)
         dp.finish()
         torch.cuda.synchronize()
