@@ -371,11 +371,39 @@ __global__ __launch_bounds__(256) void cast_transpose_k(const float* __restrict_
         if (c < C && r < R) out[(long)c * ldo + r] = from_f<TO>(tile[tx][ty + 4 * i]);
     }
 }
+// bf16 output, 16-byte accesses on both sides: float4 loads along C, 8 packed bf16 per store along R
+__global__ __launch_bounds__(256) void cast_transpose_v_k(const float* __restrict__ in, bf16* __restrict__ out, int R, int C, long ldo) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;             // 16 float4 per tile row, 16 rows per pass
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = r0 + rr + 16 * i, c = c0 + q * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R && c < C) v = *reinterpret_cast<const float4*>(in + (long)r * C + c);     // C % 4 == 0: all or nothing
+        tile[rr + 16 * i][q * 4 + 0] = v.x; tile[rr + 16 * i][q * 4 + 1] = v.y;
+        tile[rr + 16 * i][q * 4 + 2] = v.z; tile[rr + 16 * i][q * 4 + 3] = v.w;
+    }
+    __syncthreads();
+    const int ch = threadIdx.x & 7, cc = threadIdx.x >> 3;              // 8 chunks of 8 rows per output row, 32 output rows per pass
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int c = c0 + cc + 32 * i, r = r0 + ch * 8;
+        if (c < C && r < R) {                                           // R % 8 == 0: all or nothing
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = tile[ch * 8 + j][cc + 32 * i];
+            VecIO<bf16, 8>::store(out + (long)c * ldo + r, v);
+        }
+    }
+}
 extern "C" int mm_cast_transpose(const float* in, void* out, int64_t R, int64_t C, int64_t ldo, int out_dtype, void* stream) {
     MM_CHECK(in && out && R > 0 && C > 0 && ldo >= R, "cast_transpose: bad arguments");
     const dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 64));
     hipStream_t st = (hipStream_t)stream;
-    if (out_dtype == MM_BF16) hipLaunchKernelGGL(cast_transpose_k<bf16>, grid, dim3(256), 0, st, in, (bf16*)out, (int)R, (int)C, (long)ldo);
+    const bool vec = out_dtype == MM_BF16 && C % 4 == 0 && R % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0;
+    if (vec) hipLaunchKernelGGL(cast_transpose_v_k, grid, dim3(256), 0, st, in, (bf16*)out, (int)R, (int)C, (long)ldo);
+    else if (out_dtype == MM_BF16) hipLaunchKernelGGL(cast_transpose_k<bf16>, grid, dim3(256), 0, st, in, (bf16*)out, (int)R, (int)C, (long)ldo);
     else if (out_dtype == MM_F32) hipLaunchKernelGGL(cast_transpose_k<float>, grid, dim3(256), 0, st, in, (float*)out, (int)R, (int)C, (long)ldo);
     else MM_FAIL(MM_ERR_ARG, "cast_transpose: bad dtype %d", out_dtype);
     MM_LAUNCH_CHECK();

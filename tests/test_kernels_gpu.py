@@ -288,6 +288,10 @@ def test_cast_transpose_and_relu2():
         out = torch.zeros(77, 3 * 130, dtype=dt, device=d)
         ops.cast_transpose(w, out[:, 130:260])
         assert torch.equal(out[:, 130:260], w.t().to(dt)) and out[:, :130].abs().sum() == 0 and out[:, 260:].abs().sum() == 0
+        w8 = _rand(200, 132, seed=4).to(d)                          # R % 8 == 0, C % 4 == 0: the 16-byte form, ragged tiles
+        out8 = torch.zeros(132, 2 * 200 + 8, dtype=dt, device=d)
+        ops.cast_transpose(w8, out8[:, 200:400])
+        assert torch.equal(out8[:, 200:400], w8.t().to(dt)) and out8[:, :200].abs().sum() == 0 and out8[:, 400:].abs().sum() == 0
         h = _rand(37, 101, seed=2, scale=2.0).to(dt).to(d)
         a = ops.relu2_fwd(h)
         assert torch.equal(a, torch.relu(h.float()).square().to(dt))
