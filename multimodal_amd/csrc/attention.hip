@@ -565,6 +565,17 @@ __global__ void attn_delta_k(const void* __restrict__ o, const void* __restrict_
     const int h = (int)(row % H);
     const long bs = row / H;                  // b*S + s
     float acc = 0.f;
+    if (is_bf16 == 2) {                          // bf16, 8-byte aligned rows: 4 elements per lane and load
+        const bf16* op = (const bf16*)o + bs * ld_o + (long)h * d;
+        const bf16* gp = (const bf16*)d_o + bs * ld_d + (long)h * d;
+        for (int c = li * 4; c < d; c += 64) {
+            float a[4], g[4];
+            VecIO<bf16, 4>::load(op + c, a);
+            VecIO<bf16, 4>::load(gp + c, g);
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc = fmaf(a[j], g[j], acc);
+        }
+    } else
     for (int c = li; c < d; c += 16) {
         float a, g;
         if (is_bf16) { a = to_f(((const bf16*)o)[bs * ld_o + (long)h * d + c]); g = to_f(((const bf16*)d_o)[bs * ld_d + (long)h * d + c]); }
@@ -1496,7 +1507,8 @@ extern "C" int mm_prefix_attn_bwd(const void* q, const void* k, const void* v, c
     p.vec_ok = attn_vec_ok(q, k, v, ld_qkv, d, dtype) && attn_vec_ok(d_o, d_o, d_o, H * d, d, dtype);
     const long rows = B * S * H;
     hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, o, d_o, (float*)workspace, rows, (int)H, (int)S,
-                       (int)d, (long)(H * d), (long)(H * d), dtype == MM_BF16 ? 1 : 0);
+                       (int)d, (long)(H * d), (long)(H * d),
+                       dtype == MM_BF16 ? ((d % 4 == 0 && (((uintptr_t)o | (uintptr_t)d_o) % 8) == 0) ? 2 : 1) : 0);
     MM_LAUNCH_CHECK();
     static const bool force_generic = getenv("MM_ATTN_GENERIC") != nullptr;     // A/B switch for debugging
     const bool al8 = (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8) == 0 && ld_dqkv % 4 == 0;
