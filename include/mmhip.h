@@ -178,6 +178,8 @@ int mm_layerscale_bwd(const void* dout, const void* z, const float* gamma, const
 int mm_argmax_rows(const void* logits, int64_t* out, int64_t rows, int64_t V, int64_t ld, int dtype, void* stream);
 /* Decoder MLP activation relu(h)^2 (models/transformer_decoder.py:161) over n elements, and its backward
  * dh = da * 2*relu(h); dh may alias da. */
+/* DropPath per-sample factor (models/convnext.py:13-17): out[i] = floor(keep + u[i]) / keep, u = the torch.rand((B,1,1)) draw. */
+int mm_droppath_scale(const float* u, float* out, int64_t n, float keep, void* stream);
 int mm_relu2_fwd(const void* h, void* a, int64_t n, int dtype, void* stream);
 int mm_relu2_bwd(const void* h, const void* da, void* dh, int64_t n, int dtype, void* stream);
 /* relu^2 backward over [M][N] plus colsum[n] = sum_m dh[m][n], autograd's gradient of the bias of the Linear that produced h

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "mm_argmax_rows": (i32, [vp, vp, i64, i64, i64, i32, vp]),
     "mm_relu2_fwd": (i32, [vp, vp, i64, i32, vp]),
     "mm_relu2_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
+    "mm_droppath_scale": (i32, [vp, vp, i64, f32, vp]),
     "mm_relu2_bwd_colsum": (i32, [vp, vp, vp, vp, vp, sz, i64, i64, i32, vp]),
     "mm_cast_transpose": (i32, [vp, vp, i64, i64, i64, i32, vp]),
     "mm_orthograd_adamw_workspace": (sz, [i64, i64]),

@@ -409,3 +409,18 @@ extern "C" int mm_cast_transpose(const float* in, void* out, int64_t R, int64_t 
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// DropPath factor per sample (reference models/convnext.py:13-17): out[i] = floor(keep + u[i]) / keep, u = the
+// torch.rand draw.  One launch instead of ATen's add, floor and div.
+// ------------------------------------------------------------------------------------------------
+__global__ void droppath_scale_k(const float* __restrict__ u, float* __restrict__ out, int n, float keep) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = floorf(keep + u[i]) / keep;
+}
+extern "C" int mm_droppath_scale(const float* u, float* out, int64_t n, float keep, void* stream) {
+    MM_CHECK(u && out && n > 0 && keep > 0.f && keep <= 1.f, "droppath_scale: bad arguments");
+    hipLaunchKernelGGL(droppath_scale_k, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, u, out, (int)n, keep);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}

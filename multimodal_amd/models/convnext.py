@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as FN
+from .. import ops
 
 
 class DropPath(nn.Module):
@@ -21,7 +22,10 @@ class DropPath(nn.Module):
         if self.drop_prob == 0. or not self.training:
             return None
         keep = 1 - self.drop_prob
-        r = keep + torch.rand((batch, 1, 1), dtype=dtype, device=device)
+        u = torch.rand((batch, 1, 1), dtype=dtype, device=device)
+        if u.is_cuda and dtype == torch.float32:
+            return ops.droppath_scale(u, keep)             # one launch for add, floor, div
+        r = keep + u
         r.floor_()
         return (r / keep).float().view(batch).contiguous()
 

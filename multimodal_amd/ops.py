@@ -386,6 +386,14 @@ def relu2_bwd_colsum_(h: Tensor, da: Tensor):
     return da, out
 
 
+def droppath_scale(u: Tensor, keep: float) -> Tensor:
+    """floor(keep + u) / keep per element of the float32 draw u (any shape) -> flat float32 [u.numel()]."""
+    _f32(u, "u")
+    out = torch.empty(u.numel(), dtype=torch.float32, device=u.device)
+    L.check(L.lib().mm_droppath_scale(L.ptr(u), L.ptr(out), u.numel(), float(keep), L.cur_stream()), "mm_droppath_scale")
+    return out
+
+
 def cast_transpose(w: Tensor, out: Tensor) -> Tensor:
     """out[:, :] (view [C, R] with unit inner stride, bf16 or f32) = w[R, C].T in out's dtype."""
     _f32(w, "w")
