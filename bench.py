@@ -126,6 +126,34 @@ def _event_time(fn, iters=20, warmup=3):
     return s.elapsed_time(e) / iters * 1e-3
 
 
+def k2_roofline(device, C=1600, Ln=31):
+    """K2: the pointwise-conv MLP of a stage-3 ConvNeXt block (convnext.py:41-45: Linear C->4C, GELU, Linear 4C->C with
+    LayerScale + residual in the epilogues) on the MFMA GEMM `gemm_k`, bf16: SURVEY 8d flops 16*B*L*C^2 per block forward,
+    at the config batch (M = B*L = 992 rows: too few tiles to fill 256 CUs) and at a saturating batch."""
+    from multimodal_amd import ops
+    out = {"kernel": "gemm_k<bf16,128x128> x2 (pwconv1+GELU, pwconv2+LayerScale+residual)", "bound": "mfma", "unit": "TFLOP/s",
+           "peak": MFMA_BF16_PEAK_TFLOPS, "traffic": None, "shape": {"C": C, "L": Ln, "dtype": "bfloat16"}}
+    w1 = (torch.randn(4 * C, C, device=device) * 0.02).to(torch.bfloat16)
+    w2 = (torch.randn(C, 4 * C, device=device) * 0.02).to(torch.bfloat16)
+    b1 = torch.zeros(4 * C, device=device)
+    b2 = torch.zeros(C, device=device)
+    gamma = torch.ones(C, device=device)
+    for B in (32, 256):
+        M = B * Ln
+        xn = torch.randn(M, C, device=device).to(torch.bfloat16)
+        res = torch.randn(M, C, device=device).to(torch.bfloat16)
+
+        def mlp():
+            a = ops.gemm(xn, w1, M, 4 * C, C, bias=b1, act=ops.ACT_GELU)
+            return ops.gemm(a, w2, M, C, 4 * C, bias=b2, gamma=gamma, res=res)
+        t = _event_time(mlp)
+        ach = 16.0 * M * C * C / t / 1e12
+        out[f"batch{B}"] = {"rows": M, "us_per_block_fwd": round(t * 1e6, 1), "achieved": round(ach, 1),
+                            "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4)}
+    out["achieved"], out["frac"] = out["batch256"]["achieved"], out["batch256"]["frac"]
+    return out
+
+
 def attn_roofline(device, B=32, H=16, d=100, N=190, T=94):
     """K3 / K3b at the local_config shape (S = 31+N+T = 315, prompt 221, stablemax, bf16, q/k pre-rotated as in the
     model): SURVEY 8d flops 4*B*S^2*E forward, 2.5x that backward (mask sparsity not discounted), against the dense bf16
@@ -428,7 +456,7 @@ def main():
         else:
             greedy["tokens_per_s"] = greedy["tokens_per_s_per_gpu"]
         extras = {"roofline": roof, "roofline_bf16": roof_bf16, "roofline_mfma": gemm_roofline(device),
-                  "roofline_attn": attn_roofline(device), "roofline_decode": decode_roofline(device), "greedy": greedy}
+                  "roofline_k2": k2_roofline(device), "roofline_attn": attn_roofline(device), "roofline_decode": decode_roofline(device), "greedy": greedy}
         extras["roofline"]["config_batch_latency_us"] = k1_roofline(device, torch.float32, B=32, iters=50)["launch_us"]
         log("kernel rooflines done")
         if world == 1:
