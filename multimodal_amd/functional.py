@@ -395,11 +395,13 @@ def _stacked_weight_grads(params, dy2: Tensor, x2: Tensor):
     return [_weight_grad(p, dy2[:, i * r: (i + 1) * r], x2) for i, p in enumerate(params)]
 
 
-# The library GEMMs are stream-K kernels (workgroups of one launch wait for each other's partial tiles).  Two of them
-# issued from two streams share the CUs; at the config batch (B*S = 10080 rows) that has run clean over >1e5 concurrent
-# launches, but at B*S = 80640 (batch 256) the pair deadlocks reproducibly -- neither launch gets all the workgroups it
-# waits for resident.  Side-stream weight gradients are therefore limited to the row range that was validated; above it
-# they run on the main stream (at such sizes there are no idle tails left to fill anyway).
+# The library GEMMs are stream-K kernels.  The forward / dX products run persistent grids whose workgroups wait for each
+# other's partial tiles; the weight-gradient products at the config batch (K = B*S = 10080) launch one workgroup per
+# output tile (kernel trace: grids of 225/225/247/169 = the tile counts), i.e. data-parallel, no waits: on a side stream
+# they can always finish beside whatever else runs (>1e5 concurrent launches clean).  At B*S = 80640 (batch 256) the
+# library splits K across workgroups for the same shapes (grid 256): then both concurrent kernels wait on workgroups that
+# may not be resident, and the pair deadlocks reproducibly.  Side-stream weight gradients are therefore limited to the
+# row range where the dW kernels are data-parallel; above it they run on the main stream.
 DEFER_MAX_ROWS = int(os.environ.get("MM_DEFER_MAX_ROWS", "16384"))
 
 
