@@ -395,14 +395,19 @@ def _stacked_weight_grads(params, dy2: Tensor, x2: Tensor):
     return [_weight_grad(p, dy2[:, i * r: (i + 1) * r], x2) for i, p in enumerate(params)]
 
 
-# The library GEMMs are stream-K kernels.  The forward / dX products run persistent grids whose workgroups wait for each
-# other's partial tiles; the weight-gradient products at the config batch (K = B*S = 10080) launch one workgroup per
-# output tile (kernel trace: grids of 225/225/247/169 = the tile counts), i.e. data-parallel, no waits: on a side stream
-# they can always finish beside whatever else runs (>1e5 concurrent launches clean).  At B*S = 80640 (batch 256) the
-# library splits K across workgroups for the same shapes (grid 256): then both concurrent kernels wait on workgroups that
-# may not be resident, and the pair deadlocks reproducibly.  Side-stream weight gradients are therefore limited to the
-# row range where the dW kernels are data-parallel; above it they run on the main stream.
-DEFER_MAX_ROWS = int(os.environ.get("MM_DEFER_MAX_ROWS", "16384"))
+# The library GEMMs are stream-K kernels: by default their workgroups wait for each other's partial tiles whenever the
+# library decides to split tiles across workgroups.  Two such launches from two streams can starve each other -- at
+# B*S = 16380 rows and above (K of the weight-gradient products) the main-stream and side-stream GEMMs deadlocked
+# reproducibly, while at the config batch (10080 rows: the dW products happen to be one workgroup per tile) they never
+# did.  multimodal_amd/__init__.py therefore sets TENSILE_STREAMK_DATA_PARALLEL=1 (read by hipBLASLt on every call):
+# whole tiles per workgroup, no inter-workgroup waits, so any launch can always finish whatever runs beside it.  Measured:
+# no loss at batch 32, +12 % at batch 256.  If the user overrides that variable, side-stream weight gradients are limited
+# to the row range that was validated with stream-K splitting active.
+def _defer_rows_limit() -> int:
+    v = os.environ.get("MM_DEFER_MAX_ROWS")
+    if v is not None:
+        return int(v)
+    return (1 << 62) if os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1" else 12288
 
 
 class DecoderLayer(torch.autograd.Function):
@@ -491,7 +496,7 @@ class DecoderLayer(torch.autograd.Function):
             dqw, dkw, dvw = _stacked_weight_grads((qw, kw, vw), dqkv2, xa2)
             return db2, dw2, db1, dw1, dbo, dwo, dbqkv, dqw, dkw, dvw
 
-        if defer_dw and M <= DEFER_MAX_ROWS:
+        if defer_dw and M <= _defer_rows_limit():
             global _join_queued
             main, side = enter_side(x.device)
             with torch.cuda.stream(side):
