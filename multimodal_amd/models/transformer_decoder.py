@@ -129,7 +129,14 @@ class SMILESDecoder(nn.Module):
             memory = _lin(memory, self.memory_proj, dt)
         if nmr_tokens is None:
             return memory
-        return th.cat([memory, self.nmr_embed(nmr_tokens.to(memory.device)).to(dt)], dim=1)
+        return th.cat([memory, self._embed(self.nmr_embed, nmr_tokens.to(memory.device), dt)], dim=1)
+
+    @staticmethod
+    def _embed(module, idx, dt):
+        w = module.weight
+        if w.is_cuda and module.padding_idx is None and module.max_norm is None:
+            return FN.Embedding.apply(w, idx, dt)
+        return module(idx).to(dt)
 
     def forward(self, tgt, memory, nmr_tokens=None):
         B, T = tgt.shape
@@ -139,7 +146,7 @@ class SMILESDecoder(nn.Module):
         if T + M > self.max_seq_length + 256:
             raise ValueError(f"Combined sequence length ({T} + {M} = {T + M}) "
                              f"exceeds maximum length ({self.max_seq_length + 256})")
-        x = th.cat([prompt, self.smiles_embed(tgt).to(dt)], dim=1)
+        x = th.cat([prompt, self._embed(self.smiles_embed, tgt, dt)], dim=1)
         for layer in self.layers:
             x = layer(x, None, prompt_len=M)
         xt = FN.LayerNorm.apply(x[:, M:], self.final_norm.weight, self.final_norm.bias)
