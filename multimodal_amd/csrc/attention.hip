@@ -1583,23 +1583,44 @@ __global__ __launch_bounds__(256) void decode_attn_k(const DecP p) {
                 VecIO<T, VEC>::store(vc + (long)pos * d + c, vnv[k]);
             }
     }
-    // ---- pass 1: scores of cached keys 0..pos-1 (4 per iteration), the new key from registers
+    // ---- pass 1: scores of cached keys 0..pos-1 (4 per iteration), the new key from registers.  The cache rows of PF
+    // iterations are requested ahead and stay packed in registers (a wave has only its own stream to hide HBM latency
+    // with: one 1-KiB request in flight per wave is ~5 MB on the chip, Little's law at ~1 us gives the 4.8 TB/s this
+    // kernel used to reach).  Rows past the end are clamped to a valid row and masked, so no branch guards a load.
+    typedef typename VecIO<T, VEC>::raw_t raw_t;
+    constexpr int PF = CH >= 4 ? 2 : (CH == 1 ? 8 : 4);              // wide heads: fewer rows ahead, the row itself is many registers
+    const int nit = (pos + 3) >> 2;
+    auto issue = [&](const T* base, int it, raw_t (&dst)[CH]) {
+        const int j = min(it * 4 + grp, pos - 1);
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+            if (cok[k]) dst[k] = VecIO<T, VEC>::load_raw(base + (long)j * d + (k * 16 + li) * VEC);
+    };
+    raw_t buf[PF][CH];
     float mx = -INFINITY;
-    for (int j0 = 0; j0 < pos; j0 += 4) {
-        const int j = j0 + grp;
-        float dot = 0.f;
-        if (j < pos) {
 #pragma unroll
-            for (int k = 0; k < CH; k++)
-                if (cok[k]) {
-                    float kv[VEC];
-                    VecIO<T, VEC>::load(kc + (long)j * d + (k * 16 + li) * VEC, kv);
+    for (int u = 0; u < PF; u++)
+        if (u < nit) issue(kc, u, buf[u]);
+    for (int it0 = 0; it0 < nit; it0 += PF) {
 #pragma unroll
-                    for (int v = 0; v < VEC; v++) dot = fmaf(qv[k][v], kv[v], dot);
-                }
+        for (int u = 0; u < PF; u++) {
+            const int it = it0 + u;
+            if (it < nit) {                                  // wave-uniform
+                const int j = it * 4 + grp;
+                float dot = 0.f;
+#pragma unroll
+                for (int k = 0; k < CH; k++)
+                    if (cok[k]) {
+                        float kv[VEC];
+                        VecIO<T, VEC>::unpack(buf[u][k], kv);
+#pragma unroll
+                        for (int v = 0; v < VEC; v++) dot = fmaf(qv[k][v], kv[v], dot);
+                    }
+                if (it + PF < nit) issue(kc, it + PF, buf[u]);
+                dot = group_sum<16>(dot) * p.scale;
+                if (j < pos) { if (li == 0) sc[wave][j] = dot; mx = fmaxf(mx, dot); }
+            }
         }
-        dot = group_sum<16>(dot) * p.scale;
-        if (j < pos) { if (li == 0) sc[wave][j] = dot; mx = fmaxf(mx, dot); }
     }
     float dn = 0.f;
 #pragma unroll
@@ -1620,20 +1641,29 @@ __global__ __launch_bounds__(256) void decode_attn_k(const DecP p) {
     for (int k = 0; k < CH; k++)
 #pragma unroll
         for (int v = 0; v < VEC; v++) oacc[k][v] = 0.f;
-    for (int j0 = 0; j0 < pos; j0 += 4) {
-        const int j = j0 + grp;
-        if (j < pos) {
-            const float x = sc[wave][j];
-            const float w = stable ? stable_s_f(x) : __expf(x - mx);
-            lsum += w;
 #pragma unroll
-            for (int k = 0; k < CH; k++)
-                if (cok[k]) {
-                    float vv[VEC];
-                    VecIO<T, VEC>::load(vc + (long)j * d + (k * 16 + li) * VEC, vv);
+    for (int u = 0; u < PF; u++)
+        if (u < nit) issue(vc, u, buf[u]);
+    for (int it0 = 0; it0 < nit; it0 += PF) {
 #pragma unroll
-                    for (int v = 0; v < VEC; v++) oacc[k][v] = fmaf(w, vv[v], oacc[k][v]);
-                }
+        for (int u = 0; u < PF; u++) {
+            const int it = it0 + u;
+            if (it < nit) {                                  // wave-uniform
+                const int j = it * 4 + grp;
+                const bool ok = j < pos;
+                const float x = sc[wave][ok ? j : 0];
+                const float w = ok ? (stable ? stable_s_f(x) : __expf(x - mx)) : 0.f;
+                lsum += w;
+#pragma unroll
+                for (int k = 0; k < CH; k++)
+                    if (cok[k]) {
+                        float vv[VEC];
+                        VecIO<T, VEC>::unpack(buf[u][k], vv);
+#pragma unroll
+                        for (int v = 0; v < VEC; v++) oacc[k][v] = fmaf(w, vv[v], oacc[k][v]);
+                    }
+                if (it + PF < nit) issue(vc, it + PF, buf[u]);
+            }
         }
     }
     if (grp == 0) {                                      // the new token's own key/value
