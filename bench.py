@@ -27,6 +27,8 @@ CONFIGS = {
     "test_config": dict(E=768, H=4, L=8, sm=True, max_seq=95, max_nmr=190, max_mem=32),
     "real_config_mup": dict(E=2048, H=4, L=8, sm=True, max_seq=95, max_nmr=190, max_mem=32),
 }
+K1_PMC = os.path.join("profiles", "r01_k1_pmc.json")
+K4_PMC = os.path.join("profiles", "r01_k4_pmc.json")
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide)
 
@@ -79,12 +81,14 @@ def k1_roofline(device, dtype=torch.float32, B=8192, C=64, Ln=250, iters=20):
     # HBM bytes per launch from the PMC passes (cannot be collected live: rocprofv3 --pmc runs benchmarks/k1_pmc.py on
     # this same shape; benchmarks/pmc_summary.py applies the gfx950 FETCH_SIZE x2 correction) -- fp32 shape only
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
+    pmc = os.path.join(ROOT, K1_PMC)
     if dtype == torch.float32 and (B, C, Ln) == (8192, 64, 250) and os.path.exists(pmc):
         with open(pmc) as fh:
             traffic = int(json.load(fh)["traffic_bytes_per_launch"])
     return {"kernel": "dwconv7_ln_fwd_strip", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "launch_us": round(t * 1e6, 2),
+            "traffic_source": (K1_PMC + " (rocprofv3 --pmc passes over benchmarks/k1_pmc.py, same shape; not re-measured "
+                               "in this run)") if traffic is not None else None,
             "shape": {"B": B, "C": C, "L": Ln, "dtype": str(dtype).replace("torch.", "")},
             "algorithmic_bytes_per_launch": nbytes}
 
@@ -197,12 +201,14 @@ def decode_roofline(device, B=1024, H=8, d=128, Smax=238):
     nbytes = B * H * 2 * (pos + 1) * d * 2
     ach = nbytes / t / 1e9
     traffic = None              # PMC passes over benchmarks/decode_pmc.py (same shape), summarised by benchmarks/pmc_summary.py
-    pmc = os.path.join(ROOT, "profiles", "r01_k4_pmc.json")
+    pmc = os.path.join(ROOT, K4_PMC)
     if (B, H, d, Smax) == (1024, 8, 128, 238) and os.path.exists(pmc):
         with open(pmc) as fh:
             traffic = int(json.load(fh)["traffic_bytes_per_launch"])
     return {"kernel": "decode_attn_k", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "launch_us": round(t * 1e6, 2),
+            "traffic_source": (K4_PMC + " (rocprofv3 --pmc passes over benchmarks/decode_pmc.py, same shape; not "
+                               "re-measured in this run)") if traffic is not None else None,
             "algorithmic_bytes_per_launch": nbytes,
             "shape": {"B": B, "H": H, "d": d, "pos": pos, "dtype": "bfloat16", "softmax": True}}
 
@@ -332,9 +338,9 @@ def greedy_nocache(device, B=128):
             "recompute_tokens_per_s": round(B * steps / t_nocache, 1), "speedup": round(t_nocache / t_cache, 2)}
 
 
-def cpu_baseline(c, sample_b=32):
-    """The CPU oracle (oracle/restate.py, pinned against the reference) timed on the host cores: one train step
-    (forward + CE + backward + OrthoGrad + AdamW) of the same shape on a bounded batch."""
+def cpu_baseline(c, sample_b=32, timed=3):
+    """The CPU oracle (oracle/restate.py, pinned against the reference) timed on the host cores: the train step
+    (forward + CE + backward + OrthoGrad + AdamW) of the same shape at the config batch, one warm-up + `timed` steps."""
     from oracle import restate
     from oracle.shapes import state_shapes
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
@@ -358,16 +364,143 @@ def cpu_baseline(c, sample_b=32):
     params = list(sd.values())
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
     ir, nmr, tgt = synth_batch(c, sample_b, "cpu", 1234)
+
+    def step():
+        loss = restate.train_loss(sd, cfg, nmr, ir, tgt, training=True)
+        opt.zero_grad()
+        loss.backward()
+        restate.orthograd_project_(params, eps=1e-8)
+        opt.step()
+    step()                                            # warm-up (allocator, thread pool, oneDNN primitive caches)
+    times = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return {"value": round(sample_b / dt, 3), "unit": "spectra/s", "cores": cores, "kind": "port", "cpu_model": model,
+            "host_cpus_visible": os.cpu_count(),
+            "cores_note": "threads = the box's CPU share per GPU (OMP_NUM_THREADS as set by the pool), not the whole host",
+            "step_seconds": [round(t, 2) for t in times],
+            "sample": f"1 warm-up + {timed} timed train steps (fwd+CE+bwd+OrthoGrad+AdamW), median, fp32, local_config "
+                      f"shape, batch {sample_b}, N=190 T=94, {dt:.1f} s per step"}
+
+
+def spawn_ranks(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher above us: this process (which has not touched the GPU) starts
+    one rank per GPU through torch.distributed.run as a CHILD process and passes its exit code on -- exactly the command
+    the driver would have issued.  Never an exec: a process that has initialised HIP must not be replaced."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    log(f"spawning {a.gpus} ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(a, world, rank):
+    """--dry-run: the launch / rendezvous / exchange plumbing without a GPU (backend gloo, CPU tensors): each rank runs the
+    production DataParallel wrapper (buckets, hook-driven all-reduce, finish) around a small stand-in module, and rank 0
+    prints a JSON line of the same form.  Covers `--gpus N` in the CPU test-suite; measures nothing."""
+    import torch.distributed as dist
+    from multimodal_amd.dp import DataParallel
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.GELU(), torch.nn.Linear(64, 8))
+    dp = DataParallel(m, bucket_bytes=1 << 10, force_collectives=True) if world >= 1 and dist.is_initialized() else None
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(100 + rank)
+    x, y = torch.randn(8, 16, generator=g), torch.randint(0, 8, (8,), generator=g)
+    if dist.is_initialized():
+        dist.barrier()
     t0 = time.perf_counter()
-    loss = restate.train_loss(sd, cfg, nmr, ir, tgt, training=True)
-    opt.zero_grad()
-    loss.backward()
-    restate.orthograd_project_(params, eps=1e-8)
-    opt.step()
-    dt = time.perf_counter() - t0
-    return {"value": round(sample_b / dt, 3), "unit": "spectra/s", "cores": cores, "kind": "port",
-            "sample": f"1 train step (fwd+CE+bwd+OrthoGrad+AdamW), fp32, local_config shape, batch {sample_b}, "
-                      f"N=190 T=94, {dt:.1f} s"}
+    for _ in range(a.steps):
+        dp.zero_grad() if dp else opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(m(x), y)
+        (dp.scale_loss(loss) if dp else loss).backward()
+        if dp:
+            dp.finish()
+        opt.step()
+    if dist.is_initialized():
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if dist.is_initialized():
+        tl = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([elapsed], dtype=torch.float64))
+        per_rank = [float(t) for t in tl]
+        chk = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "replicas diverged"
+    if rank == 0:
+        print(json.dumps({"metric": "train spectra/sec", "value": None, "unit": "spectra/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "dry_run": True, "backend": a.backend, "rccl_ranks": world,
+                          "allreduce_calls": dp.n_allreduce if dp else 0, "replicas_equal": True,
+                          "per_rank_ms_per_step": [round(t / max(1, a.steps) * 1e3, 3) for t in per_rank]}), flush=True)
+
+
+def rccl_world1_leg(c, device, steps=5):
+    """N = 1 only: the SAME train step with the process group initialised on the nccl (= RCCL) backend and every bucket
+    all-reduce forced through it (one rank; a second rank cannot share the device): proof, in the driver's own N = 1 run,
+    that the communicator, the hook-driven asynchronous all-reduce on RCCL's stream and finish() execute on this GPU."""
+    import socket
+    import torch.distributed as dist
+    import multimodal_amd as mm
+    from multimodal_amd.dp import DataParallel
+    from multimodal_amd.optim import OrthoGradAdamW
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        with mm.compute_dtype(torch.bfloat16):
+            model = build_model(c, device).train()
+            dp = DataParallel(model, force_collectives=True)
+            opt = OrthoGradAdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, ortho=True,
+                                 ortho_eps=1e-8, rescale=True)
+            ir, nmr, tgt = synth_batch(c, 32, device, 4)
+            crit = torch.nn.CrossEntropyLoss(ignore_index=0)
+
+            def step():
+                dp.zero_grad()
+                logits = model(nmr, ir, tgt[:, :-1], None)
+                dp.scale_loss(crit(logits.reshape(-1, logits.size(-1)), tgt[:, 1:].reshape(-1))).backward()
+                dp.finish()
+                opt.step()
+            for _ in range(3):
+                step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            n0 = dp.n_allreduce
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            out = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "ms_per_step": round(dt * 1e3, 2),
+                   "allreduce_calls_per_step": (dp.n_allreduce - n0) // steps, "buckets": len(dp.buckets.buckets),
+                   "bucket_mib": [round(b["flat"].numel() * 4 / 2 ** 20, 1) for b in dp.buckets.buckets],
+                   "overlap_hooks": bool(dp.overlap)}
+        del model, dp, opt
+        torch.cuda.empty_cache()
+    finally:
+        dist.destroy_process_group()
+    return out
 
 
 def main():
@@ -379,18 +512,38 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (configs/*.yaml: training.batch_size = 32)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / greedy / cpu baseline legs")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend: nccl (= RCCL, the product path) or gloo (CPU plumbing check, --dry-run)")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous + DataParallel plumbing on CPU tensors, no GPU, no timing")
     a = ap.parse_args()
 
     import torch.distributed as dist
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if a.dry_run:
+        if a.backend != "gloo":
+            raise SystemExit("bench.py --dry-run runs on CPU tensors: use --backend gloo")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            assert dist.get_world_size() == a.gpus
+        dry_run(a, world, rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if a.backend != "nccl":
+        raise SystemExit("bench.py: measured runs use --backend nccl (RCCL); gloo is for --dry-run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        assert dist.get_world_size() == a.gpus and dist.get_backend() == "nccl"
 
     log(f"torch {torch.__version__} up, device {torch.cuda.get_device_name(local)}, world {world}")
     import multimodal_amd as mm
@@ -401,6 +554,7 @@ def main():
     mm.set_compute_dtype(dt)
     model = build_model(c, device).train()
     dp = DataParallel(model)
+    assert dp.world == world and (world == 1 or (dp.collective and dp.overlap and not dp.host_staged))
     # optimizer of configs/local_config.yaml: ortho_adamw, lr 1e-4, betas (0.9,0.999), wd 0.01, ortho eps 1e-8, rescale
     opt = OrthoGradAdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, ortho=True,
                          ortho_eps=1e-8, rescale=True)
@@ -428,6 +582,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     log(f"timing {a.steps} steps")
+    n_ar0 = dp.n_allreduce
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
@@ -435,12 +590,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
     if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        tl = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([elapsed], device=device, dtype=torch.float64))
+        per_rank = [float(t.item()) for t in tl]
+        elapsed = max(per_rank)                   # MAX over ranks
     final_loss = float(loss_acc.item()) / max(1, a.steps + a.warmup)
     log(f"train leg: {elapsed / a.steps * 1e3:.2f} ms/step")
+    rccl = {"backend": "nccl" if world > 1 else None, "ranks": world,
+            "allreduce_calls_per_step": (dp.n_allreduce - n_ar0) // max(1, a.steps),
+            "buckets": len(dp.buckets.buckets), "bucket_mib": [round(b["flat"].numel() * 4 / 2 ** 20, 1) for b in dp.buckets.buckets],
+            "per_rank_ms_per_step": [round(t / a.steps * 1e3, 3) for t in per_rank]}
 
     extras = {}
     if not a.no_extras:
@@ -468,8 +629,10 @@ def main():
             extras["train_batch32_fp32"] = train_leg(c, device, 32, torch.float32, steps=5, warmup=2)
             log("captured-step leg")
             extras["hip_graph_step"] = graph_leg(device)
+            log("RCCL one-rank leg")
+            extras["rccl_world1"] = rccl_world1_leg(c, device)
         if rank == 0 and world == 1:
-            log("CPU baseline (oracle, one train step on the host cores)")
+            log("CPU baseline (oracle, train steps on the host cores)")
             extras["cpu_baseline"] = cpu_baseline(c)
             log("CPU baseline done")
 
@@ -484,7 +647,7 @@ def main():
                                    f"T={c['max_seq'] - 1} S={31 + c['max_nmr'] + c['max_seq'] - 1}",
                        "global_batch": gb, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "master_weights": "f32", "random_init": True},
-            "mean_loss": round(final_loss, 4),
+            "mean_loss": round(final_loss, 4), "rccl_ranks": world if world > 1 else 0, "rccl": rccl,
         }
         out.update(extras)
         print(json.dumps(out), flush=True)

@@ -1,6 +1,9 @@
 """MI355X-native hot path of tomoqt/multimodal (spectra -> SMILES): ConvNeXt-1D encoder, prompt-decoder attention,
-KV-cached greedy decode, data-parallel training.  All arithmetic of the hot path runs in libmmhip (hand-written HIP for
-gfx950) behind the C ABI in include/mmhip.h; there is no CPU or eager fallback."""
+KV-cached greedy decode, data-parallel training.  The path's own kernels -- depthwise conv + LayerNorm, the encoder's
+GEMMs with fused epilogues, prefix-LM / decode attention, LayerNorm, RoPE, relu^2, the fused optimizer, and the decoder
+products routed to the large-tile GEMM -- are hand-written HIP for gfx950 in libmmhip behind the C ABI of
+include/mmhip.h.  The remaining plain decoder GEMMs run on hipBLASLt through torch.mm, embedding gathers and the
+cross-entropy on ATen (DESIGN.md 1 lists exactly which).  There is no CPU or eager fallback for the libmmhip part."""
 import os as _os
 
 # hipBLASLt's GEMMs are stream-K kernels whose workgroups wait for each other's partial tiles; two of them launched from

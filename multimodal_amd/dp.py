@@ -10,6 +10,8 @@ parameter order (the order backward produces gradients).  Bucket size defaults t
 point-to-point (7 links x ~153 GB/s), large messages keep every link busy and 288 GB of HBM makes them free."""
 from __future__ import annotations
 
+import os
+from contextlib import contextmanager
 from typing import List, Optional
 
 import torch
@@ -106,25 +108,36 @@ class DataParallel:
     defaults to True when the process group's backend is gloo, False for nccl (= RCCL)."""
 
     def __init__(self, module: torch.nn.Module, process_group=None, bucket_bytes: int = 128 << 20, overlap: bool = True,
-                 host_staged: Optional[bool] = None):
+                 host_staged: Optional[bool] = None, force_collectives: Optional[bool] = None):
+        """force_collectives (default: env MM_DP_FORCE_COLLECTIVES=1): issue the broadcast and every bucket all-reduce
+        even when the process group has ONE rank -- the whole RCCL path (communicator, async all-reduce on RCCL's stream,
+        hook-driven launches) then runs on a one-GPU box, where a second rank cannot share the device."""
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if force_collectives is None:
+            force_collectives = os.environ.get("MM_DP_FORCE_COLLECTIVES") == "1"
+        self.collective = dist.is_initialized() and (self.world > 1 or bool(force_collectives))
         if host_staged is None:
             host_staged = dist.is_initialized() and dist.get_backend(process_group) == "gloo"
         self.host_staged = host_staged
         adjacent = [g for m in module.modules() if hasattr(m, "stacked_grad_groups") for g in m.stacked_grad_groups()]
         self.buckets = GradBuckets(list(module.parameters()), bucket_bytes, adjacent=adjacent)
-        self.overlap = overlap and self.world > 1
+        self.overlap = overlap and self.collective
         self._bucket_of = {}
         for b in self.buckets.buckets:
             for p in b["params"]:
                 self._bucket_of[p] = b
-        if self.world > 1:
+        if self.collective:
             self.broadcast_parameters()
         self.optimizer = None
         self._prescaled = False
         self._hooked = False
+        self._accumulating = False
+        self._finished = False
+        self._backward_done = False
+        self._cb_queued = False
+        self.n_allreduce = 0              # collectives issued so far (bench.py reports it: proof the exchange ran)
         if self.overlap:
             self._install_hooks()
 
@@ -154,6 +167,7 @@ class DataParallel:
 
     def _all_reduce(self, flat):
         """Sum `flat` over the ranks, ordered after the current stream's work; returns a handle with wait()."""
+        self.n_allreduce += 1
         if flat.is_cuda and self.host_staged:
             h = flat.cpu()                       # synchronises with the current stream
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
@@ -169,23 +183,33 @@ class DataParallel:
         dev = b["flat"].device
         if dev.type != "cuda":
             self.buckets.gather(b)
-            if self.world > 1:
+            if self.collective:
                 b["work"] = self._all_reduce(b["flat"])
             return
         main, side = FN.enter_side(dev)
         with torch.cuda.stream(side):
             self.buckets.gather(b)
-            if self.world > 1:
+            if self.collective:
                 b["work"] = self._all_reduce(b["flat"])
             if self.optimizer is not None:
-                if self.world > 1:
+                if self.collective:
                     b["work"].wait()
-                    if not self._prescaled:
+                    if not self._prescaled and self.world > 1:
                         b["flat"].mul_(1.0 / self.world)
                     b["scaled"] = True
                 self.optimizer.step_subset(b["params"], id(b))
 
     def _hook(self, p):
+        if self._accumulating:        # inside accumulate(): gradients pile up in place, nothing is counted or reduced
+            return
+        if self.collective:
+            if self._backward_done:
+                raise RuntimeError("DataParallel: a second backward() since zero_grad() -- its buckets are already "
+                                   "reduced.  For gradient accumulation run every backward but the last inside "
+                                   "`with dp.accumulate():`")
+            if not self._cb_queued:   # the engine calls this back when the backward pass that fired this hook is over
+                self._cb_queued = True
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
         b = self._bucket_of[p]
         if id(p) in b["fired"]:       # a node that wrote p.grad itself has reported it; autograd's own hook may follow
             return
@@ -194,14 +218,32 @@ class DataParallel:
         if b["pending"] == 0:
             self._launch(b)
 
+    def _end_of_backward(self):
+        self._cb_queued = False
+        self._backward_done = True
+
     def scale_loss(self, loss):
         """loss / world for this step's backward: the summed all-reduce then IS the rank average and finish() skips its
         division pass over every gradient (one read+write of all parameters' worth of HBM per step)."""
         self._prescaled = True
         return loss if self.world == 1 else loss * (1.0 / self.world)
 
+    @contextmanager
+    def accumulate(self):
+        """Gradient accumulation over several backward passes: run all but the LAST backward of a step inside this
+        context.  Inside it no bucket is counted, reduced or updated (the gradients accumulate in place in their bucket
+        slots); the last backward, outside it, fires the hooks and the ONE all-reduce per bucket."""
+        prev, self._accumulating = self._accumulating, True
+        try:
+            yield self
+        finally:
+            self._accumulating = prev
+
     def zero_grad(self):
         self._prescaled = False
+        self._finished = False
+        self._backward_done = False
+        self._cb_queued = False
         self.buckets.zero()
         for b in self.buckets.buckets:
             b["pending"] = len(b["params"])
@@ -215,16 +257,20 @@ class DataParallel:
     def finish(self):
         """Complete, reduce (and average) every bucket.  Parameters that received no gradient this step still take part
         (their bucket slots are zero), so every rank issues the same collectives in the same order."""
+        if self._finished and self.collective:
+            raise RuntimeError("DataParallel.finish() called twice without zero_grad(): the buckets are already reduced")
         for b in self.buckets.buckets:
             if not b.get("launched", False):
                 self._launch(b)
         FN.join_side_stream()
-        if self.world > 1:
+        if self.collective:
             for b in self.buckets.buckets:
                 if not b.get("scaled", False):
                     b["work"].wait()
-                    if not self._prescaled:
+                    if not self._prescaled and self.world > 1:
                         b["flat"].mul_(1.0 / self.world)
+                    b["scaled"] = True
+        self._finished = True
 
     def __call__(self, *a, **kw):
         return self.module(*a, **kw)

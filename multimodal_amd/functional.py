@@ -95,6 +95,23 @@ def main_stream(device) -> torch.cuda.Stream:
 _keepalive = []      # tensors the side stream still reads (kept referenced until the main stream has joined it)
 
 
+def _order_accumulation(pairs, main, side) -> None:
+    """pairs: (parameter, gradient this node returns for it, produced on the side stream).  Autograd keeps a returned
+    gradient as it is when the parameter's .grad is unset (no kernel), but ACCUMULATES into an existing .grad
+    (`p.grad += g`, gradient accumulation, a second backward, zero_grad(set_to_none=False)) on the MAIN stream, and the
+    engine orders that only after the node's own main-stream work.  In that case the main stream must wait for the side
+    stream here, before the node returns."""
+    if any(g is not None and p.grad is not None for p, g in pairs):
+        main.wait_stream(side)
+
+
+def _new_graph_root() -> None:
+    """A forward pass in training mode starts: any earlier backward is over, whether it completed or raised, so a join
+    flag left set by a backward that raised (its end-of-backward callback never ran) must not suppress the next one."""
+    global _join_queued
+    _join_queued = False
+
+
 def join_side_stream() -> None:
     """Make the current stream wait for every side-stream gradient launch issued so far."""
     global _join_queued
@@ -147,7 +164,9 @@ class ConvNeXtBlock(torch.autograd.Function):
         out = ops.gemm(a, w2c, M, Cc, 4 * Cc, bias=b2.detach(), pre=z, gamma=g, rowscale=dp_scale, rows_per_scale=Ln,
                        res=x.view(M, Cc))
         if train:
+            _new_graph_root()
             ctx.save_for_backward(x, dw_w, dw_b, ln_w, mean, rstd, xn, h, a, z, w1, w2, gamma, dp_scale)
+            ctx.b1 = b1
         return out.view(B, Ln, Cc)
 
     @staticmethod
@@ -174,6 +193,7 @@ class ConvNeXtBlock(torch.autograd.Function):
         _keepalive.append((dz, dh, a, xn))     # incl. saved activations (freed when this node is released)
         for t in (dw2, db1, dw1):
             t.record_stream(main)
+        _order_accumulation(((w2, dw2), (ctx.b1, db1), (w1, dw1)), main, side)
         if not _join_queued:
             _join_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
@@ -462,6 +482,8 @@ class DecoderLayer(torch.autograd.Function):
             ctx.save_for_backward(x, mean1, rstd1, xa, qkv, o, lse, x1, mean2, rstd2, xf, h, a, cos_t, sin_t,
                                   ln1w, qw, kw, vw, ow, ln2w, w1, w2)
             ctx.cfg = (H, rot, prompt_len, stablemax, bool(defer_dw))
+            ctx.biases = (qb, kb, vb, ob, b1, b2)
+            _new_graph_root()
         return out.view(B, S, D)
 
     @staticmethod
@@ -528,6 +550,10 @@ class DecoderLayer(torch.autograd.Function):
             for t in grads:
                 if t is not None:
                     t.record_stream(main)
+            g_db2, g_dw2, g_db1, g_dw1, g_dbo, g_dwo, g_dbqkv, g_dqw, g_dkw, g_dvw = grads
+            qb, kb, vb, ob, b1, b2 = ctx.biases
+            _order_accumulation(((w2, g_dw2), (b2, g_db2), (w1, g_dw1), (b1, g_db1), (ow, g_dwo), (ob, g_dbo), (qw, g_dqw),
+                                 (kw, g_dkw), (vw, g_dvw), (qb, g_dbqkv), (kb, g_dbqkv), (vb, g_dbqkv)), main, side)
             if not _join_queued:
                 _join_queued = True
                 torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)

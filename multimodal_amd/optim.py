@@ -32,7 +32,8 @@ class OrthoGradAdamW(torch.optim.Optimizer):
                         rescale=rescale)
         super().__init__(params, defaults)
         self._tables = {}
-        self._step = 0
+        self._step = 0                # steps opened so far (torch AdamW's per-parameter `step` = _step - _skipped[p])
+        self._skipped = {}            # id(p) -> steps in which p had no gradient (torch does not count those for p)
         self.capturable = bool(capturable)
         self._hyper = None            # [n_groups, 4] float32 on the device: lr, 1-b1^t, sqrt(1-b2^t), pad
         self._hyper_host = None
@@ -62,9 +63,16 @@ class OrthoGradAdamW(torch.optim.Optimizer):
         ev.record()
         self._hyper_ev[slot] = ev
 
-    @staticmethod
-    def _key(plist, shadows):
-        return tuple((p.data_ptr(), p.grad.data_ptr(), 0 if s is None else s.data_ptr()) for p, s in zip(plist, shadows))
+    def _key(self, plist, shadows):
+        """The static part of a descriptor table: parameter, moment and operand-copy addresses (load_state_dict replaces
+        the moment tensors; .to()/.data= move parameters).  Gradient addresses are patched separately (_patch_grads)."""
+        out = []
+        for p, s in zip(plist, shadows):
+            st = self.state.get(p, {})
+            m, v = st.get("exp_avg"), st.get("exp_avg_sq")
+            out.append((p.data_ptr(), 0 if m is None else m.data_ptr(), 0 if v is None else v.data_ptr(),
+                        0 if s is None else s.data_ptr()))
+        return tuple(out)
 
     def _build(self, slot, plist, shadows):
         dev = plist[0].device
@@ -83,16 +91,33 @@ class OrthoGradAdamW(torch.optim.Optimizer):
             ct += [t] * nch
             co += [i * CHUNK for i in range(nch)]
             tcs.append(tcs[-1] + nch)
-        raw = np.frombuffer(bytes(descs), dtype=np.uint8)
+        host = np.frombuffer(bytes(descs), dtype=np.int64).reshape(len(plist), 6).copy()     # p, g, m, v, n, w16
         tab = dict(
-            key=self._key(plist, shadows),
-            descs=torch.from_numpy(raw.copy()).to(dev),
+            key=self._key(plist, shadows), host=host, gkey=tuple(p.grad.data_ptr() for p in plist),
+            descs=torch.from_numpy(host.view(np.uint8).reshape(-1).copy()).to(dev),
             ct=torch.tensor(ct, dtype=torch.int32, device=dev), co=torch.tensor(co, dtype=torch.int64, device=dev),
             tcs=torch.tensor(tcs, dtype=torch.int32, device=dev), n_tensors=len(plist), n_chunks=len(ct))
         self._tables[slot] = tab
         return tab
 
-    def _run(self, slot, group, plist):
+    @staticmethod
+    def _patch_grads(tab, plist):
+        """Without gradient buckets autograd hands over fresh gradient tensors every step: only the g column of the
+        descriptor table moves.  It is patched on the host copy and uploaded with ONE asynchronous copy from pinned
+        memory (the caching host allocator keeps the staging block until the copy has run) -- no table rebuild, no
+        synchronous pageable uploads."""
+        gkey = tuple(p.grad.data_ptr() for p in plist)
+        if gkey == tab["gkey"]:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("OrthoGradAdamW: gradient addresses moved under graph capture (use dp.DataParallel's "
+                               "gradient buckets, whose slots are fixed)")
+        tab["host"][:, 1] = gkey
+        stage = torch.from_numpy(tab["host"].view(np.uint8).reshape(-1)).pin_memory()
+        tab["descs"].copy_(stage, non_blocking=True)
+        tab["gkey"] = gkey
+
+    def _run(self, slot, group, plist, step=None):
         """One OrthoGrad+AdamW launch sequence over plist with group's hyper-parameters, on the current stream."""
         for p in plist:
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
@@ -100,9 +125,16 @@ class OrthoGradAdamW(torch.optim.Optimizer):
         # bf16 GEMM-operand copies the model keeps of these parameters (functional.cached_operand): the update
         # refreshes them in the same pass, so no cast kernels run in the next forward
         shadows = [FN.shadow_of(p) for p in plist]
+        for p in plist:                 # moments exist before the key is taken (their addresses are part of it)
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         tab = self._tables.get(slot)
         if tab is None or tab["key"] != self._key(plist, shadows):
             tab = self._build(slot, plist, shadows)
+        else:
+            self._patch_grads(tab, plist)
         nbytes = L.lib().mm_orthograd_adamw_workspace(tab["n_tensors"], tab["n_chunks"])
         ws = ops.workspace(nbytes, plist[0].device, "optim")
         b1, b2 = group["betas"]
@@ -118,7 +150,8 @@ class OrthoGradAdamW(torch.optim.Optimizer):
             return
         L.check(L.lib().mm_orthograd_adamw(L.ptr(tab["descs"]), L.ptr(tab["ct"]), L.ptr(tab["co"]), L.ptr(tab["tcs"]),
                                            tab["n_tensors"], tab["n_chunks"], CHUNK, group["lr"], b1, b2, group["eps"],
-                                           group["weight_decay"], self._step, group["ortho_eps"], int(group["rescale"]),
+                                           group["weight_decay"], int(self._step if step is None else step),
+                                           group["ortho_eps"], int(group["rescale"]),
                                            int(group["ortho"]), L.ptr(ws), nbytes, L.cur_stream()), "mm_orthograd_adamw")
         # the kernel writes through raw pointers: tell autograd (and functional.cached_operand) the values moved
         torch.autograd.graph.increment_version(plist)
@@ -143,7 +176,8 @@ class OrthoGradAdamW(torch.optim.Optimizer):
             if gi is not None and p.grad is not None and id(p) not in self._done:
                 by_group.setdefault(gi, []).append(p)
         for gi, plist in by_group.items():
-            self._run(("subset", tag, gi), self.param_groups[gi], plist)
+            for j, (stp, sub) in enumerate(self._by_step(plist)):
+                self._run(("subset", tag, gi, j), self.param_groups[gi], sub, stp)
             self._done.update(id(p) for p in plist)
 
     @torch.no_grad()
@@ -160,11 +194,76 @@ class OrthoGradAdamW(torch.optim.Optimizer):
         FN.join_side_stream()
         for gi, group in enumerate(self.param_groups):
             plist = [p for p in group["params"] if p.grad is not None and id(p) not in done]
-            if plist:
-                self._run(("all" if not begun else "rest", gi), group, plist)
+            for j, (stp, sub) in enumerate(self._by_step(plist)):
+                self._run(("all" if not begun else "rest", gi, j), group, sub, stp)
+            for p in group["params"]:                # torch.optim.AdamW advances `step` only for parameters it updates
+                if p.grad is None and id(p) not in done:
+                    self._skipped[id(p)] = self._skipped.get(id(p), 0) + 1
         self._begun = False
         self._done = set()
         return loss
+
+    def _by_step(self, plist):
+        """[(step, parameters)] -- one entry unless some parameter sat out earlier steps (it then lags, as in torch)."""
+        groups = {}
+        for p in plist:
+            groups.setdefault(self._step - self._skipped.get(id(p), 0), []).append(p)
+        if self.capturable and (len(groups) > 1 or any(k != self._step for k in groups)):
+            raise RuntimeError("OrthoGradAdamW(capturable=True): every parameter must receive a gradient every step")
+        return sorted(groups.items())
+
+    # ---- checkpoint layout of the reference (ortho_grad.py:111-129: the wrapper's own state is empty, the wrapped AdamW's
+    # state_dict sits under 'base_optimizer' with torch's per-parameter {'step', 'exp_avg', 'exp_avg_sq'})
+    def state_dict(self):
+        sd = super().state_dict()
+        order = [p for g in self.param_groups for p in g["params"]]
+        state = {}
+        for idx, st in sd["state"].items():
+            st = dict(st)
+            st["step"] = torch.tensor(float(self._step - self._skipped.get(id(order[idx]), 0)), dtype=torch.float32)
+            state[idx] = st
+        groups = sd["param_groups"]
+        return {"state": {}, "param_groups": groups,
+                "base_optimizer": {"state": state, "param_groups": [dict(g) for g in groups]}}
+
+    def load_state_dict(self, state_dict):
+        """Accepts this class's state_dict() and the reference's OrthoGrad(AdamW) checkpoints (same layout; its groups
+        carry one 'eps' for both the projection and AdamW and no 'ortho*' keys).  The caller's dict is not modified."""
+        base = state_dict.get("base_optimizer")
+        if base is not None:
+            state, groups = base["state"], (state_dict.get("param_groups") or base["param_groups"])
+        else:
+            state, groups = state_dict["state"], state_dict["param_groups"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        merged = []
+        for cur, saved in zip(self.param_groups, groups):
+            g = {k: v for k, v in cur.items() if k != "params"}
+            for k in ("lr", "betas", "eps", "weight_decay", "rescale", "ortho", "ortho_eps"):
+                if k in saved:
+                    g[k] = tuple(saved[k]) if k == "betas" else saved[k]
+            if "ortho_eps" not in saved and "eps" in saved:
+                g["ortho_eps"] = saved["eps"]
+            g["params"] = list(saved["params"])
+            merged.append(g)
+        steps, clean = {}, {}
+        for idx, st in state.items():
+            st = dict(st)
+            stp = st.pop("step", None)
+            steps[int(idx)] = 0 if stp is None else int(float(stp))
+            clean[idx] = {k: v for k, v in st.items() if k in ("exp_avg", "exp_avg_sq")}
+        super().load_state_dict({"state": clean, "param_groups": merged})
+        order = [p for g in self.param_groups for p in g["params"]]
+        flat_ids = [i for g in merged for i in g["params"]]
+        self._step = max(steps.values(), default=0)
+        self._skipped = {}
+        for pos, idx in enumerate(flat_ids):
+            if int(idx) in steps and steps[int(idx)] != self._step:
+                self._skipped[id(order[pos])] = self._step - steps[int(idx)]
+        # every cached device table points at the replaced moment tensors / an older step
+        self._tables.clear()
+        self._begun = False
+        self._done = set()
 
 
 def OrthoGrad(params, base_optimizer_cls=torch.optim.AdamW, eps: float = 1e-30, rescale: bool = True, **base_optimizer_args):

@@ -98,3 +98,79 @@ def test_two_rank_gradients_equal_single_rank_on_concatenated_batch(dtype):
             assert rel_err(torch.from_numpy(g), p.grad.float().cpu()) < tol, k
     finally:
         mm.set_compute_dtype(torch.float32)
+
+
+def _rccl_worker(port, q):
+    """One rank on the nccl (= RCCL) backend with every collective forced: communicator creation, broadcast, the
+    hook-driven asynchronous bucket all-reduce on RCCL's stream, finish(), accumulate() and the second-backward guard."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device(DEV)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    res = {}
+    try:
+        from multimodal_amd.dp import DataParallel
+        m = _build(torch.float32)
+        dp = DataParallel(m, bucket_bytes=1 << 20, force_collectives=True)
+        assert dp.collective and dp.overlap and not dp.host_staged and dist.get_backend() == "nccl"
+        ir, nmr, tgt = case_inputs(CASE)
+        n_tok = int((tgt[:, 1:] != 0).sum())
+        for _ in range(2):
+            dp.zero_grad()
+            dp.scale_loss(_loss(m, ir, nmr, tgt, n_tok)).backward()
+            launched = sum(bool(b.get("launched")) for b in dp.buckets.buckets)
+            dp.finish()
+        torch.cuda.synchronize()
+        res["launched"] = launched
+        res["n_allreduce"] = dp.n_allreduce
+        res["n_buckets"] = len(dp.buckets.buckets)
+        res["grads"] = [p.grad.detach().float().cpu().numpy() for p in m.parameters()]
+        # a second backward without zero_grad() would add to reduced buckets: refused, not silently wrong
+        try:
+            _loss(m, ir, nmr, tgt, n_tok).backward()
+            res["second_backward"] = "accepted"
+        except RuntimeError as e:
+            res["second_backward"] = str(e)
+        # gradient accumulation: first micro-batch inside accumulate(), ONE all-reduce per bucket at the end
+        dp.zero_grad()
+        n0 = dp.n_allreduce
+        h = CASE["B"] // 2
+        with dp.accumulate():
+            _loss(m, ir[:h], nmr[:h], tgt[:h], n_tok).backward()
+        assert dp.n_allreduce == n0
+        _loss(m, ir[h:], nmr[h:], tgt[h:], n_tok).backward()
+        dp.finish()
+        torch.cuda.synchronize()
+        res["accum_allreduce"] = dp.n_allreduce - n0
+        res["accum_grads"] = [p.grad.detach().float().cpu().numpy() for p in m.parameters()]
+    finally:
+        q.put(res)
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_one_rank_runs_the_exchange_path():
+    """The nccl backend IS RCCL on ROCm.  A one-GPU box cannot host a second rank on the card, so the product's exchange
+    path runs here with one rank and forced collectives: results must equal the plain single-process gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29800 + os.getpid() % 1000, q))
+    p.start()
+    try:
+        res = q.get(timeout=240)
+    finally:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    assert p.exitcode == 0 and "grads" in res, res.keys()
+    assert res["launched"] > 0 and res["n_allreduce"] == 2 * res["n_buckets"] and res["n_buckets"] > 2
+    assert "accumulate" in res["second_backward"]
+    assert res["accum_allreduce"] == res["n_buckets"]
+    m = _build(torch.float32)
+    ir, nmr, tgt = case_inputs(CASE)
+    n_tok = int((tgt[:, 1:] != 0).sum())
+    _loss(m, ir, nmr, tgt, n_tok).backward()
+    for (k, prm), g, ga in zip(m.named_parameters(), res["grads"], res["accum_grads"]):
+        assert rel_err(torch.from_numpy(g), prm.grad.float().cpu()) < 1e-6, k
+        assert rel_err(torch.from_numpy(ga), prm.grad.float().cpu()) < 2e-5, k       # two half batches: other sum order

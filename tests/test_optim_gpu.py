@@ -61,3 +61,72 @@ def test_reference_signature_rejects_other_bases():
     p = [torch.nn.Parameter(torch.zeros(3, device=DEV))]
     with pytest.raises(NotImplementedError):
         OrthoGrad(p, base_optimizer_cls=torch.optim.SGD, lr=0.1)
+
+
+def _mk(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(300, 70), (70,), (129, 513), (1,), (5, 3, 7)]
+    return [torch.randn(s, generator=g) * 0.1 for s in shapes]
+
+
+def _grads(t, seed=100):
+    g = torch.Generator().manual_seed(seed + t)
+    return [torch.randn(p.shape, generator=g) for p in _mk()]
+
+
+def test_save_load_step_equals_uninterrupted_run():
+    """state_dict() keeps the per-parameter step (torch AdamW's layout under 'base_optimizer', ortho_grad.py:111-117):
+    3 steps + save + load into a NEW optimizer + 3 steps == 6 uninterrupted steps, bit for bit, including a parameter
+    that sits out step 1 (its bias correction lags by one step, as in torch) and fresh gradient tensors every step
+    (no buckets: only the gradient column of the device table moves)."""
+    from multimodal_amd.optim import OrthoGradAdamW
+
+    def run(split):
+        ps = [torch.nn.Parameter(p.clone().to(DEV)) for p in _mk()]
+        opt = OrthoGradAdamW(ps, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01, ortho_eps=1e-8)
+        for t in range(6):
+            if split and t == 3:
+                sd = opt.state_dict()
+                assert set(sd) == {"state", "param_groups", "base_optimizer"} and sd["state"] == {}
+                st = sd["base_optimizer"]["state"]
+                assert float(st[0]["step"]) == 3.0 and float(st[1]["step"]) == 2.0       # p1 sat out step 1
+                sd = {k: (v if k != "base_optimizer" else {"state": {i: {n: (x.clone() if torch.is_tensor(x) else x)
+                                                                            for n, x in e.items()} for i, e in v["state"].items()},
+                                                             "param_groups": v["param_groups"]}) for k, v in sd.items()}
+                opt = OrthoGradAdamW(ps, lr=1.0)                     # other hyper-parameters: the checkpoint's must win
+                opt.load_state_dict(sd)
+                assert opt.param_groups[0]["lr"] == 1e-2 and opt.param_groups[0]["betas"] == (0.9, 0.99)
+            for i, (p, g) in enumerate(zip(ps, _grads(t))):
+                p.grad = None if (i == 1 and t == 1) else g.to(DEV)
+            opt.step()
+        torch.cuda.synchronize()
+        return [p.detach().cpu() for p in ps]
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_loads_reference_layout_checkpoint_fields():
+    """A checkpoint dict shaped like the reference's OrthoGrad(AdamW).state_dict() (no 'ortho*' keys, one shared eps,
+    torch AdamW's extra group keys) loads; moments land on the GPU; the next update uses step + 1."""
+    from multimodal_amd.optim import OrthoGradAdamW
+    ps = [torch.nn.Parameter(p.clone().to(DEV)) for p in _mk()]
+    groups = [dict(eps=1e-8, rescale=True, lr=2e-4, betas=(0.9, 0.999), weight_decay=0.05, amsgrad=False, maximize=False,
+                   foreach=None, capturable=False, differentiable=False, fused=None, params=list(range(len(ps))))]
+    state = {i: dict(step=torch.tensor(7.0), exp_avg=torch.full_like(p, 0.01).cpu(), exp_avg_sq=torch.full_like(p, 1e-4).cpu())
+             for i, p in enumerate(ps)}
+    ref_sd = {"state": {}, "param_groups": groups, "base_optimizer": {"state": state, "param_groups": [dict(g) for g in groups]}}
+    opt = OrthoGradAdamW(ps, lr=1.0)
+    opt.load_state_dict(ref_sd)
+    g = opt.param_groups[0]
+    assert (g["lr"], g["weight_decay"], g["eps"], g["ortho_eps"], g["ortho"]) == (2e-4, 0.05, 1e-8, 1e-8, True)
+    assert opt._step == 7 and opt.state[ps[0]]["exp_avg"].is_cuda
+    assert "base_optimizer" in ref_sd                               # the caller's dict is left intact
+    before = [p.detach().clone() for p in ps]
+    for p, gr in zip(ps, _grads(0)):
+        p.grad = gr.to(DEV)
+    opt.step()
+    torch.cuda.synchronize()
+    assert opt._step == 8 and float(opt.state_dict()["base_optimizer"]["state"][0]["step"]) == 8.0
+    assert all(not torch.equal(a, p.detach()) for a, p in zip(before, ps))
