@@ -120,6 +120,13 @@ size_t mm_colsum_workspace(int64_t M, int64_t N);
 int mm_colsum(const void* x, float* out, void* workspace, size_t workspace_bytes, int64_t M, int64_t N,
               int64_t ld, int dtype, void* stream);
 
+/* mm_colsum without a workspace argument and without any allocation.  No counterpart in the reference: it exists for
+ * callers that cannot allocate or carry a workspace -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  The [chunks][N] partial sums live in a 5 MiB device array built into the library (one copy per GPU,
+ * held until the process ends), so N <= 8192 (larger N: MM_ERR_ARG, use mm_colsum).  Results are bit-identical to mm_colsum.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams) race. */
+int mm_colsum_noalloc(const void* x, float* out, int64_t M, int64_t N, int64_t ld, int dtype, void* stream);
+
 /* ---- K3: prefix-LM attention with partial RoPE, softmax or stablemax ----------------------
  * replaces models/transformer_decoder.py:129-153 (+ the mask of :295-298, built in-kernel).
  * q,k,v: [B][S][H][d] with row stride ld_qkv elements between consecutive s (so a fused [B][S][3E]

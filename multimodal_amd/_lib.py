@@ -53,6 +53,7 @@ _SIGNATURES = {
     "mm_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "mm_colsum_workspace": (sz, [i64, i64]),
     "mm_colsum": (i32, [vp, vp, vp, sz, i64, i64, i64, i32, vp]),
+    "mm_colsum_noalloc": (i32, [vp, vp, i64, i64, i64, i32, vp]),
     "mm_prefix_attn_fwd": (i32, [vp] * 7 + [i64] * 7 + [i32, i32, vp]),
     "mm_prefix_attn_bwd_workspace": (sz, [i64, i64, i64]),
     "mm_prefix_attn_bwd": (i32, [vp] * 11 + [vp, sz] + [i64] * 8 + [i32, i32, vp]),

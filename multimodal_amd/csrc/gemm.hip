@@ -11,6 +11,7 @@
 // The MFMA is issued as (B-fragment, A-fragment): D's register index then runs along N, so every lane
 // owns 4 consecutive output columns and the epilogue moves 8/16 bytes per lane.
 #include "common.h"
+#include <mutex>
 #include "gemm_epi.h"
 #include <stdlib.h>
 
@@ -409,6 +410,52 @@ extern "C" int mm_colsum(const void* x, float* out, void* workspace, size_t work
     hipLaunchKernelGGL(colsum_stage2_k, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, (const float*)workspace, out, nchunks, (int)N);
     MM_LAUNCH_CHECK();
     return MM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mm_colsum for callers that cannot allocate or hand over a workspace (code under HIP graph capture, serving loops):
+// the [nchunks][N] partial sums live in a file-scope device array.  Each GPU holds its own copy of the array at its own
+// address: the address is looked up once per device (hipGetSymbolAddress, with that device current) and that pointer --
+// never the array's name, which in host code is only a stand-in -- is what the kernels receive.
+// ------------------------------------------------------------------------------------------------
+#define MM_COLSUM_NOALLOC_MAX_N 8192                       /* 4 * d_model of the widest config (E = 2048) */
+#define MM_COLSUM_NOALLOC_MAX_CHUNKS 160                   /* colsum_chunks()'s cap */
+static __device__ __align__(256) float scratch[MM_COLSUM_NOALLOC_MAX_CHUNKS * MM_COLSUM_NOALLOC_MAX_N];   // 5 MiB per GPU
+#define MM_MAX_DEVICES 64
+static float* g_scratch_ptr[MM_MAX_DEVICES];               // per device; written once, under g_scratch_mu
+static std::mutex g_scratch_mu;
+
+static int colsum_scratch_for_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) MM_FAIL(MM_ERR_LAUNCH, "colsum_noalloc: hipGetDevice failed: %s", hipGetErrorString(e));
+    MM_CHECK(dev >= 0 && dev < MM_MAX_DEVICES, "colsum_noalloc: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        float* ptr = nullptr;
+        e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr)
+            MM_FAIL(MM_ERR_LAUNCH, "colsum_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return MM_OK;
+}
+
+extern "C" int mm_colsum_noalloc(const void* x, float* out, int64_t M, int64_t N, int64_t ld, int dtype, void* stream) {
+    MM_CHECK(x && out, "colsum_noalloc: null pointer");
+    MM_CHECK(M > 0 && N > 0 && ld >= N, "colsum_noalloc: bad shape");
+    MM_CHECK(N <= MM_COLSUM_NOALLOC_MAX_N,
+             "colsum_noalloc: N=%lld exceeds the built-in scratch (max N = %d); use mm_colsum with a caller workspace",
+             (long long)N, MM_COLSUM_NOALLOC_MAX_N);
+    MM_CHECK(mm_colsum_workspace(M, N) <= sizeof(float) * MM_COLSUM_NOALLOC_MAX_CHUNKS * MM_COLSUM_NOALLOC_MAX_N,
+             "colsum_noalloc: shape needs more than the built-in scratch");
+    float* ptr = nullptr;
+    int rc = colsum_scratch_for_current_device(&ptr);
+    if (rc != MM_OK) return rc;
+    // stage 1 writes every partial that stage 2 reads ([nchunks][N], dense), so nothing has to start at zero and the
+    // previous call's contents are harmless; two calls that overlap on one GPU (two streams) race on the array.
+    return mm_colsum(x, out, ptr, sizeof(float) * MM_COLSUM_NOALLOC_MAX_CHUNKS * MM_COLSUM_NOALLOC_MAX_N, M, N, ld, dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

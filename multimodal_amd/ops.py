@@ -241,6 +241,19 @@ def colsum(x: Tensor, M: int, N: int, tag: str = "ws") -> Tensor:
     return out
 
 
+def colsum_noalloc(x: Tensor, out: Tensor) -> Tensor:
+    """out[n] = sum_m x[m][n] through mm_colsum_noalloc: no workspace argument, nothing allocated by the call (out is
+    the caller's).  For callers under HIP graph capture / serving loops; N <= 8192."""
+    if not x.is_cuda or x.dim() != 2 or x.stride(1) != 1:
+        raise RuntimeError("colsum_noalloc: expected a 2-D GPU tensor with unit inner stride")
+    M, N = x.shape
+    if not out.is_cuda or out.dtype != torch.float32 or out.numel() != N or not out.is_contiguous():
+        raise RuntimeError("colsum_noalloc: out must be a contiguous float32 GPU tensor of N elements")
+    L.check(L.lib().mm_colsum_noalloc(L.ptr(x), L.ptr(out), M, N, x.stride(0), L.dtype_code(x), L.cur_stream()),
+            "mm_colsum_noalloc")
+    return out
+
+
 # --------------------------------------------------------------------------- attention
 _rope_cache = {}
 
