@@ -99,6 +99,13 @@ if __name__ == "__main__":
             for (B, C, Ln) in [(8192, 64, 250), (8192, 256, 62), (2048, 1600, 31)]:
                 res.append(bench_k1(B, C, Ln, dt)); print(json.dumps(res[-1]), flush=True)
             res.append(bench_k1(8192, 64, 250, dt, bwd=True)); print(json.dumps(res[-1]), flush=True)
+    if "k1all" in a.what.split(","):     # the four stage shapes x dtype x fwd/bwd at a saturating batch (compact lines)
+        for dt in (torch.float32, torch.bfloat16):
+            for (B, C, Ln) in [(8192, 64, 250), (8192, 128, 125), (8192, 256, 62), (2048, 1600, 31), (2048, 2048, 31)]:
+                for bwd in (False, True):
+                    r = bench_k1(B, C, Ln, dt, bwd=bwd)
+                    print(f"K1 {'bwd' if bwd else 'fwd'} {str(dt)[6:]:8s} B{B} C{C} L{Ln}: {r['us']:8.1f} us {r['GBps']:7.0f} GB/s "
+                          f"({r['GBps'] / 8000:.3f} of 8 TB/s)", flush=True)
     if "k1" in a.what.split(","):
         for dt in (torch.float32, torch.bfloat16):
             for (B, C, Ln) in [(8192, 64, 250), (8192, 128, 125), (8192, 256, 62), (4096, 1600, 31), (32, 64, 250), (32, 256, 62), (32, 1600, 31)]:

@@ -47,6 +47,7 @@ template <> struct VecIO<float, 4> {
     // raw form: keep the 16 loaded bytes packed until they are needed (several rows in flight per lane)
     typedef mm_f4_t raw_t;
     static __device__ __forceinline__ raw_t load_raw(const float* p) { return *reinterpret_cast<const mm_f4_t*>(p); }
+    static __device__ __forceinline__ raw_t load_raw_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const mm_f4_t*>(p)); }
     static __device__ __forceinline__ void unpack(raw_t t, float (&v)[4]) { v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
     // non-temporal forms for once-touched streams (measured on K1: +4% fwd stores, +10% bwd loads)
     static __device__ __forceinline__ void load_nt(const float* p, float (&v)[4]) {
@@ -69,6 +70,7 @@ template <> struct VecIO<float, 1> {
 template <> struct VecIO<bf16, 8> {
     typedef mm_u4_t raw_t;
     static __device__ __forceinline__ raw_t load_raw(const bf16* p) { return *reinterpret_cast<const mm_u4_t*>(p); }
+    static __device__ __forceinline__ raw_t load_raw_nt(const bf16* p) { return load_raw(p); }
     static __device__ __forceinline__ void unpack(raw_t t, float (&v)[8]) {
 #pragma unroll
         for (int i = 0; i < 4; i++) { v[2 * i] = __uint_as_float(t[i] << 16); v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u); }
@@ -91,6 +93,7 @@ template <> struct VecIO<bf16, 8> {
 template <> struct VecIO<bf16, 4> {
     typedef mm_u2_t raw_t;
     static __device__ __forceinline__ raw_t load_raw(const bf16* p) { return *reinterpret_cast<const mm_u2_t*>(p); }
+    static __device__ __forceinline__ raw_t load_raw_nt(const bf16* p) { return load_raw(p); }
     static __device__ __forceinline__ void unpack(raw_t t, float (&v)[4]) {
         v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
         v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
@@ -137,6 +140,29 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+
+// Wave-wide sum returned as a wave-UNIFORM value (it lives in an SGPR): 4 DPP steps inside each row of 16 lanes, then
+// row_bcast:15 / row_bcast:31 carry the row totals into lane 63, which v_readlane reads.  No LDS permute, no wait; the
+// callers below only need the total on one lane (to post it) or as a scalar operand.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_f_rows(float v) {      // rows outside ROW_MASK get 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_u(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);                  // every lane: the sum of its row of 16
+    v += dpp_f_rows<0x142, 0xA>(v);        // row_bcast:15 -> rows 1 and 3 add the total of the row before them
+    v += dpp_f_rows<0x143, 0xC>(v);        // row_bcast:31 -> rows 2 and 3 add lane 31 (= rows 0+1): lane 63 holds the wave total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// Sum over the first 8 lanes of a wave (lanes 8..63 may hold anything), uniform result.
+__device__ __forceinline__ float first8_sum_u(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);                  // row_half_mirror: lanes 0..7 of a row now hold the sum of those 8 lanes
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
 
 // Block-wide sum for blockDim.x == NW*64; red must hold NW floats; contains ONE __syncthreads().
 template <int NW> __device__ __forceinline__ float block_sum(float v, float* red) {

@@ -20,10 +20,20 @@
 #define RINGF 8          // 7 taps + (RINGF-7) rows of prefetch; the walk is unrolled RINGF times so slot indices are static
 #endif
 
+static __device__ __forceinline__ void IO_f4(const float* p, float (&v)[4]) {          // 16-byte parameter load (L1/L2 resident)
+    const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward, channels-last input, strip kernel
+//
+// Row pipeline per strip: the 7-row window lives unpacked in an 8-slot register ring (slot of row r = (r - l0 + 3) mod 8,
+// static after unrolling by 8); QD further rows are IN FLIGHT in a queue of packed 16-byte registers.  No branch guards a
+// load: row indices are clamped into the sample and rows outside it are zeroed by a select when they enter the window
+// (a guarded load makes the compiler wait for it inside its branch -- measured: every row load was followed by
+// s_waitcnt vmcnt(0), i.e. no prefetch at all).  Straight-line loads let it count: vmcnt(QD-1).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int VEC, int LPR>
+template <typename T, int VEC, int LPR, int QD>
 __global__ __launch_bounds__(256) void dwconv7_ln_fwd_strip(const T* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ cb, const float* __restrict__ lw,
                                                            const float* __restrict__ lb, T* __restrict__ y,
@@ -31,6 +41,10 @@ __global__ __launch_bounds__(256) void dwconv7_ln_fwd_strip(const T* __restrict_
                                                            int B, int L, int TL, int sps, float eps) {
     constexpr int SPW = 64 / LPR;
     constexpr int C = VEC * LPR;
+    constexpr int RING = 8;
+    static_assert(RING % QD == 0, "queue depth must divide the ring");
+    typedef VecIO<T, VEC> IO;
+    typedef typename IO::raw_t raw_t;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int li = lane % LPR;
@@ -52,30 +66,38 @@ __global__ __launch_bounds__(256) void dwconv7_ln_fwd_strip(const T* __restrict_
         for (int t = 0; t < 7; t++) wt[t][v] = w[(c0 + v) * 7 + t];
         bias[v] = cb[c0 + v]; g[v] = lw[c0 + v]; be[v] = lb[c0 + v];
     }
-    float win[RINGF][VEC];
-    auto load_row = [&](int l, float (&dst)[VEC]) {
-        if (l >= 0 && l < L) VecIO<T, VEC>::load(xb + (long)l * C, dst);
-        else {
+    auto fetch = [&](int l) -> raw_t { return IO::load_raw(xb + (long)min(max(l, 0), L - 1) * C); };   // always in bounds
+    auto enter = [&](raw_t r, int l, float (&dst)[VEC]) {                   // unpack; rows outside the sample are zero padding
+        IO::unpack(r, dst);
+        const bool pad = (l < 0) | (l >= L);
 #pragma unroll
-            for (int v = 0; v < VEC; v++) dst[v] = 0.f;
-        }
+        for (int v = 0; v < VEC; v++) dst[v] = pad ? 0.f : dst[v];
     };
+    float win[RING][VEC];
+    raw_t q[QD];
+    {
+        raw_t head[6];
 #pragma unroll
-    for (int s = 0; s < RINGF - 1; s++) load_row(l0 - 3 + s, win[s]);      // rows l0-3 .. l0+RINGF-5
-
+        for (int s = 0; s < 6; s++) head[s] = fetch(l0 - 3 + s);            // rows l0-3 .. l0+2
+#pragma unroll
+        for (int s = 0; s < QD; s++) q[s] = fetch(l0 + 3 + s);              // rows l0+3 .. in flight
+#pragma unroll
+        for (int s = 0; s < 6; s++) enter(head[s], l0 - 3 + s, win[s]);
+    }
     const float invC = 1.0f / (float)C;
-    for (int base = l0; base < l1; base += RINGF) {
+    for (int base = l0; base < l1; base += RING) {
 #pragma unroll
-        for (int i = 0; i < RINGF; i++) {
+        for (int i = 0; i < RING; i++) {
             const int l = base + i;
-            load_row(l + RINGF - 4, win[(i + RINGF - 1) % RINGF]);            // prefetch RINGF-7 rows ahead
+            enter(q[i % QD], l + 3, win[(i + 6) % RING]);                   // row l+3 completes the window of row l
+            q[i % QD] = fetch(l + 3 + QD);
             float acc[VEC];
             float s1 = 0.f;
 #pragma unroll
             for (int v = 0; v < VEC; v++) {
                 float a = bias[v];
 #pragma unroll
-                for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], win[(i + t) % RINGF][v], a);
+                for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], win[(i + t) % RING][v], a);
                 acc[v] = a; s1 += a;
             }
             const float mu = group_sum<LPR>(s1) * invC;
@@ -87,7 +109,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_fwd_strip(const T* __restrict_
                 float o[VEC];
 #pragma unroll
                 for (int v = 0; v < VEC; v++) o[v] = fmaf(acc[v] * rs, g[v], be[v]);
-                VecIO<T, VEC>::store_nt(yb + (long)l * C, o);
+                IO::store_nt(yb + (long)l * C, o);
                 if (mean_out && li == 0) { mean_out[(long)b * L + l] = mu; rstd_out[(long)b * L + l] = rs; }
             }
         }
@@ -95,75 +117,161 @@ __global__ __launch_bounds__(256) void dwconv7_ln_fwd_strip(const T* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward, channels-last input, wide kernel: block = 256 threads per strip, CH chunks of VEC per thread
+// forward, channels-last input, wide kernel (any C up to NT*CH*4): one NT-thread workgroup per strip, a thread owns CH
+// chunks of 4 channels.  Same row pipeline as the strip kernel (8-slot register window, QD packed rows in flight, no
+// branch guards a load): every input row is loaded ONCE per strip.  LayerNorm needs sums over the whole row, i.e. over the
+// workgroup: rows are finished in groups of R = 4, so the two cross-wave reductions (mean, then centred variance) cost two
+// barriers per 4 rows instead of per row; the per-wave partials of the 4 rows travel through LDS as one float4.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int VEC, int CH>
-__global__ __launch_bounds__(256) void dwconv7_ln_fwd_wide(const T* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ cb, const float* __restrict__ lw,
-                                                          const float* __restrict__ lb, T* __restrict__ y,
-                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                          int B, int C, int L, int TL, int sps, float eps) {
-    __shared__ float red[2][4];
+template <typename T, int NT, int CH, int QD>
+__global__ __launch_bounds__(NT) void dwconv7_ln_fwd_wide(const T* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ cb, const float* __restrict__ lw,
+                                                         const float* __restrict__ lb, T* __restrict__ y,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                         int B, int C, int L, int TL, int sps, float eps) {
+    constexpr int VEC = 4, RING = 8, R = 4, NW = NT / 64;
+    static_assert(RING % QD == 0, "queue depth must divide the ring");
+    typedef VecIO<T, VEC> IO;
+    typedef typename IO::raw_t raw_t;
+    __shared__ __attribute__((aligned(16))) float red[2][2][NW][R];      // [parity of the group][mean | M2][wave][row]
     const int b = blockIdx.x / sps;
     const int l0 = (blockIdx.x % sps) * TL;
     const int l1 = min(l0 + TL, L);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const T* xb = x + (long)b * L * C;
     T* yb = y + (long)b * L * C;
     int cidx[CH]; bool cok[CH];
-    float wt[CH][7][VEC], bias[CH][VEC], g[CH][VEC], be[CH][VEC];
+    float wt[CH][7][VEC], bias[CH][VEC];
+    int mine = 0;                                 // channels this thread really owns
 #pragma unroll
     for (int k = 0; k < CH; k++) {
-        cidx[k] = (k * 256 + threadIdx.x) * VEC;
-        cok[k] = cidx[k] < C;
+        const int c = (k * NT + threadIdx.x) * VEC;
+        cok[k] = c < C;
+        cidx[k] = cok[k] ? c : 0;                 // idle threads shadow chunk 0 (valid addresses), contribute nothing
+        mine += cok[k] ? VEC : 0;
 #pragma unroll
-        for (int v = 0; v < VEC; v++) {
-            const int c = cok[k] ? cidx[k] + v : 0;
+        for (int v = 0; v < VEC; v++)
 #pragma unroll
-            for (int t = 0; t < 7; t++) wt[k][t][v] = w[c * 7 + t];
-            bias[k][v] = cb[c]; g[k][v] = lw[c]; be[k][v] = lb[c];
-        }
+            for (int t = 0; t < 7; t++) wt[k][t][v] = w[(cidx[k] + v) * 7 + t];
+        IO_f4(cb + cidx[k], bias[k]);
+    }
+    const float n_w = wave_sum_u((float)mine);    // channels of this wave
+    const float inv_nw = n_w > 0.f ? 1.0f / n_w : 0.f;
+    auto fetch = [&](int l, int k) -> raw_t { return IO::load_raw(xb + (long)min(max(l, 0), L - 1) * C + cidx[k]); };
+    auto enter = [&](raw_t r, int l, float (&dst)[VEC]) {
+        IO::unpack(r, dst);
+        const bool pad = (l < 0) | (l >= L);
+#pragma unroll
+        for (int v = 0; v < VEC; v++) dst[v] = pad ? 0.f : dst[v];
+    };
+    float win[CH][RING][VEC];
+    raw_t q[CH][QD];
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        raw_t head[6];
+#pragma unroll
+        for (int s = 0; s < 6; s++) head[s] = fetch(l0 - 3 + s, k);
+#pragma unroll
+        for (int s = 0; s < QD; s++) q[k][s] = fetch(l0 + 3 + s, k);
+#pragma unroll
+        for (int s = 0; s < 6; s++) enter(head[s], l0 - 3 + s, win[k][s]);
+    }
+    // lane j < NW: the channel count of wave j (wave j owns channels [(k*NT + j*64)*4, +256) of each chunk k); 0 elsewhere
+    float cntl = 0.f;
+    static_assert(NW <= 8, "the cross-wave step reduces over at most 8 lanes");
+    if (lane < NW) {
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < CH; k++) n += max(0, min(C - (k * NT + lane * 64) * VEC, 64 * VEC));
+        cntl = (float)n;
     }
     const float invC = 1.0f / (float)C;
-    for (int l = l0; l < l1; l++) {
-        float acc[CH][VEC];
-        float s1 = 0.f;
+    float acc[R][CH][VEC];
+    int grp = 0;
+    for (int base = l0; base < l1; base += RING) {
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
+        for (int i = 0; i < RING; i++) {
+            const int l = base + i;
+            const int r = i % R;
 #pragma unroll
-            for (int v = 0; v < VEC; v++) acc[k][v] = bias[k][v];
-            if (cok[k]) {
+            for (int k = 0; k < CH; k++) {
+                enter(q[k][i % QD], l + 3, win[k][(i + 6) % RING]);
+                q[k][i % QD] = fetch(l + 3 + QD, k);
+            }
+            __builtin_amdgcn_sched_barrier(0);    // the scheduler would sink the loads to their use (QD rows later): pin them here
 #pragma unroll
-                for (int t = 0; t < 7; t++) {
-                    const int ll = l + t - 3;
-                    if (ll >= 0 && ll < L) {
-                        float r[VEC];
-                        VecIO<T, VEC>::load(xb + (long)ll * C + cidx[k], r);
+            for (int k = 0; k < CH; k++) {
 #pragma unroll
-                        for (int v = 0; v < VEC; v++) acc[k][v] = fmaf(wt[k][t][v], r[v], acc[k][v]);
-                    }
+                for (int v = 0; v < VEC; v++) {
+                    float a = bias[k][v];
+#pragma unroll
+                    for (int t = 0; t < 7; t++) a = fmaf(wt[k][t][v], win[k][(i + t) % RING][v], a);
+                    acc[r][k][v] = a;
                 }
+            }
+            if (r != R - 1) continue;
+            // ---- the group's 4 rows.  Per wave: mean and centred sum of squares over the wave's own channels (two-pass,
+            // DPP only); across the waves the (count, mean, M2) triples are combined exactly (M2 = sum M2_w + sum n_w
+            // (mean_w - mean)^2): two-pass accuracy with ONE barrier per 4 rows.
+            float g[CH][VEC], be[CH][VEC];
 #pragma unroll
-                for (int v = 0; v < VEC; v++) s1 += acc[k][v];
+            for (int k = 0; k < CH; k++) { IO_f4(lw + cidx[k], g[k]); IO_f4(lb + cidx[k], be[k]); }   // issued before the barrier
+            float mw[R], m2w[R];
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < CH; k++)
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) t += cok[k] ? acc[rr][k][v] : 0.f;
+                mw[rr] = wave_sum_u(t) * inv_nw;                 // wave-uniform (SGPR)
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < CH; k++)
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) { const float dlt = acc[rr][k][v] - mw[rr]; t = cok[k] ? fmaf(dlt, dlt, t) : t; }
+                m2w[rr] = wave_sum_u(t);
+            }
+            const int par = grp & 1;
+            grp++;
+            if (lane == 0) {
+                *reinterpret_cast<float4*>(red[par][0][wave]) = make_float4(mw[0], mw[1], mw[2], mw[3]);
+                *reinterpret_cast<float4*>(red[par][1][wave]) = make_float4(m2w[0], m2w[1], m2w[2], m2w[3]);
+            }
+            __syncthreads();
+            // lane j < NW holds wave j's (mean, M2) of the 4 rows; 3 DPP steps over those lanes give the row statistics
+            const int jw = lane < NW ? lane : 0;
+            float4 pm = *reinterpret_cast<const float4*>(red[par][0][jw]);
+            float4 p2 = *reinterpret_cast<const float4*>(red[par][1][jw]);
+            if (lane >= NW) { pm = make_float4(0.f, 0.f, 0.f, 0.f); p2 = pm; }
+            float mu[R], var[R];
+            mu[0] = first8_sum_u(cntl * pm.x) * invC; mu[1] = first8_sum_u(cntl * pm.y) * invC;
+            mu[2] = first8_sum_u(cntl * pm.z) * invC; mu[3] = first8_sum_u(cntl * pm.w) * invC;
+            { float dlt;
+              dlt = pm.x - mu[0]; var[0] = first8_sum_u(fmaf(cntl * dlt, dlt, p2.x));
+              dlt = pm.y - mu[1]; var[1] = first8_sum_u(fmaf(cntl * dlt, dlt, p2.y));
+              dlt = pm.z - mu[2]; var[2] = first8_sum_u(fmaf(cntl * dlt, dlt, p2.z));
+              dlt = pm.w - mu[3]; var[3] = first8_sum_u(fmaf(cntl * dlt, dlt, p2.w)); }
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) {
+                const int lr = l - (R - 1) + rr;
+                const float rs = rsqrtf(var[rr] * invC + eps);
+                if (lr < l1) {
+#pragma unroll
+                    for (int k = 0; k < CH; k++)
+                        if (cok[k]) {
+                            float o[VEC];
+#pragma unroll
+                            for (int v = 0; v < VEC; v++) o[v] = fmaf((acc[rr][k][v] - mu[rr]) * rs, g[k][v], be[k][v]);
+                            IO::store_nt(yb + (long)lr * C + cidx[k], o);
+                        }
+                    if (mean_out && threadIdx.x == 0) { mean_out[(long)b * L + lr] = mu[rr]; rstd_out[(long)b * L + lr] = rs; }
+                }
             }
         }
-        const float mu = block_sum<4>(s1, red[0]) * invC;
-        float s2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < CH; k++)
-            if (cok[k]) {
-#pragma unroll
-                for (int v = 0; v < VEC; v++) { acc[k][v] -= mu; s2 = fmaf(acc[k][v], acc[k][v], s2); }
-            }
-        const float rs = rsqrtf(block_sum<4>(s2, red[1]) * invC + eps);
-#pragma unroll
-        for (int k = 0; k < CH; k++)
-            if (cok[k]) {
-                float o[VEC];
-#pragma unroll
-                for (int v = 0; v < VEC; v++) o[v] = fmaf(acc[k][v] * rs, g[k][v], be[k][v]);
-                VecIO<T, VEC>::store(yb + (long)l * C + cidx[k], o);
-            }
-        if (mean_out && threadIdx.x == 0) { mean_out[(long)b * L + l] = mu; rstd_out[(long)b * L + l] = rs; }
     }
 }
 
@@ -229,7 +337,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_fwd_bcl(const T* __restrict__ 
 // workspace; dwconv7_ln_bwd_reduce adds the rows in a fixed order (deterministic).
 // Workspace row layout: [7][C] dw (tap-major), [C] db, [C] dln_w, [C] dln_b  = 10*C floats.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int VEC, int LPR>
+template <typename T, int VEC, int LPR, int QD, bool HAS_RES>
 __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict__ x, const T* __restrict__ dy,
                                                            const T* __restrict__ dres, const float* __restrict__ w,
                                                            const float* __restrict__ cb, const float* __restrict__ lw,
@@ -239,6 +347,10 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
     constexpr int SPW = 64 / LPR;
     constexpr int C = VEC * LPR;
     constexpr int NP = 10;                       // partial vectors per channel
+    constexpr int RING = 8;
+    static_assert(RING % QD == 0, "queue depth must divide the ring");
+    typedef VecIO<T, VEC> IO;
+    typedef typename IO::raw_t raw_t;
     __shared__ float acc_lds[4 * SPW][NP * C];   // 4*SPW strips * 10*C floats = 40 KiB for every (VEC,LPR)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -255,6 +367,9 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
     const long rowbase = (long)b * L;
     const T* xb = x + rowbase * C + c0;
     const T* dyb = dy + rowbase * C + c0;
+    const T* drb = HAS_RES ? dres + rowbase * C + c0 : nullptr;
+    const float* mub = mean + rowbase;
+    const float* rsb = rstd + rowbase;
     T* dxb = dx + rowbase * C + c0;
 
     float wt[7][VEC], bias[VEC], g[VEC];
@@ -271,47 +386,62 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
         for (int t = 0; t < 7; t++) pdw[t][v] = 0.f;
         pdb[v] = 0.f; pdg[v] = 0.f; pdbeta[v] = 0.f;
     }
-    float xw[RINGB][VEC], dc[RINGB][VEC];
-    auto load_x = [&](int l, float (&dst)[VEC]) {
-        if (l >= 0 && l < L) VecIO<T, VEC>::load_nt(xb + (long)l * C, dst);
-        else {
+    // Row pipeline as in the forward kernel: no branch guards a load.  Row indices are clamped into the sample, rows
+    // outside it are zeroed by selects when they are consumed; x, dy, (mean, rstd) and dres each keep QD rows in flight.
+    auto clampl = [&](int l) -> long { return (long)min(max(l, 0), L - 1); };
+    auto enter = [&](raw_t r, bool pad, float (&dst)[VEC]) {
+        IO::unpack(r, dst);
 #pragma unroll
-            for (int v = 0; v < VEC; v++) dst[v] = 0.f;
-        }
+        for (int v = 0; v < VEC; v++) dst[v] = pad ? 0.f : dst[v];
     };
-    // the walk starts at l = l0-3: x ring slots 0..6 hold rows l0-6 .. l0
+    float xw[RING][VEC], dc[RING][VEC];
+    raw_t qx[QD], qdy[QD], qdr[QD];
+    float qmu[QD], qrs[QD];
+    const int lw0 = l0 - 3;                      // first row of the walk
+    {
+        raw_t head[6];
 #pragma unroll
-    for (int s = 0; s < RINGB - 1; s++) load_x(l0 - 6 + s, xw[s]);
+        for (int s = 0; s < 6; s++) head[s] = IO::load_raw_nt(xb + clampl(lw0 - 3 + s) * C);        // rows l0-6 .. l0-1
 #pragma unroll
-    for (int s = 0; s < RINGB; s++)
+        for (int s = 0; s < QD; s++) {
+            qx[s] = IO::load_raw_nt(xb + clampl(lw0 + 3 + s) * C);
+            qdy[s] = IO::load_raw_nt(dyb + clampl(lw0 + s) * C);
+            qmu[s] = mub[clampl(lw0 + s)];
+            qrs[s] = rsb[clampl(lw0 + s)];
+            if (HAS_RES) qdr[s] = IO::load_raw_nt(drb + clampl(lw0 - 3 + s) * C);
+        }
+#pragma unroll
+        for (int s = 0; s < 6; s++) { const int r = lw0 - 3 + s; enter(head[s], (r < 0) | (r >= L), xw[s]); }
+    }
+#pragma unroll
+    for (int s = 0; s < RING; s++)
 #pragma unroll
         for (int v = 0; v < VEC; v++) dc[s][v] = 0.f;
 
     const float invC = 1.0f / (float)C;
     const int lend = l1 + 3;
-    for (int base = l0 - 3; base < lend; base += RINGB) {
+    for (int base = lw0; base < lend; base += RING) {
 #pragma unroll
-        for (int i = 0; i < RINGB; i++) {
+        for (int i = 0; i < RING; i++) {
             const int l = base + i;                         // row whose dconv is produced now
-            load_x(l + RINGB - 4, xw[(i + RINGB - 1) % RINGB]);   // prefetch RINGB-7 rows ahead
-            const bool inrow = (l >= 0 && l < L && l < lend);
+            const int k = i % QD;
+            enter(qx[k], (l + 3 < 0) | (l + 3 >= L), xw[(i + 6) % RING]);      // row l+3 completes the window of row l
+            qx[k] = IO::load_raw_nt(xb + clampl(l + 3 + QD) * C);
             // rows outside the image are computed on zeros (mu = rs = 0 -> dconv = 0): control flow stays
             // uniform, so the DPP sums always run with full EXEC
+            const bool inrow = (l >= 0) & (l < L) & (l < lend);
             float gy[VEC], xh[VEC], gg[VEC], d[VEC];
-            float mu = 0.f, rs = 0.f;
-            if (inrow) {
-                VecIO<T, VEC>::load_nt(dyb + (long)l * C, gy);
-                mu = mean[rowbase + l]; rs = rstd[rowbase + l];
-            } else {
-#pragma unroll
-                for (int v = 0; v < VEC; v++) gy[v] = 0.f;
-            }
+            enter(qdy[k], !inrow, gy);
+            const float mu = inrow ? qmu[k] : 0.f, rs = inrow ? qrs[k] : 0.f;
+            qdy[k] = IO::load_raw_nt(dyb + clampl(l + QD) * C);
+            qmu[k] = mub[clampl(l + QD)];
+            qrs[k] = rsb[clampl(l + QD)];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int v = 0; v < VEC; v++) {
                 float a = bias[v];
 #pragma unroll
-                for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], xw[(i + t) % RINGB][v], a);
+                for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], xw[(i + t) % RING][v], a);
                 xh[v] = (a - mu) * rs;
                 gg[v] = gy[v] * g[v];
                 s1 += gg[v]; s2 = fmaf(gg[v], xh[v], s2);
@@ -327,28 +457,30 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
                     pdbeta[v] += gy[v];
                     pdb[v] += d[v];
 #pragma unroll
-                    for (int t = 0; t < 7; t++) pdw[t][v] = fmaf(d[v], xw[(i + t) % RINGB][v], pdw[t][v]);
+                    for (int t = 0; t < 7; t++) pdw[t][v] = fmaf(d[v], xw[(i + t) % RING][v], pdw[t][v]);
                 }
             }
 #pragma unroll
-            for (int v = 0; v < VEC; v++) dc[i][v] = d[v];  // dconv ring slot of row l is i (RINGB == unroll)
+            for (int v = 0; v < VEC; v++) dc[i][v] = d[v];  // dconv ring slot of row l is i (RING == unroll)
             // dx(l-3) = sum_t w[t] * dconv(l-3-t+3) = sum_t w[t] * dconv(l-t)
             const int lo = l - 3;
-            if (live && lo >= l0 && lo < l1) {
-                float o[VEC];
-                if (dres) VecIO<T, VEC>::load_nt(dres + (rowbase + lo) * C + c0, o);
-                else {
+            float o[VEC];
+            if (HAS_RES) {
+                IO::unpack(qdr[k], o);
+                qdr[k] = IO::load_raw_nt(drb + clampl(lo + QD) * C);
+            } else {
 #pragma unroll
-                    for (int v = 0; v < VEC; v++) o[v] = 0.f;
-                }
+                for (int v = 0; v < VEC; v++) o[v] = 0.f;
+            }
+            if (live && lo >= l0 && lo < l1) {
 #pragma unroll
                 for (int v = 0; v < VEC; v++) {
                     float a = o[v];
 #pragma unroll
-                    for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], dc[(i - t + RINGB) % RINGB][v], a);
+                    for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], dc[(i - t + RING) % RING][v], a);
                     o[v] = a;
                 }
-                VecIO<T, VEC>::store_nt(dxb + (long)lo * C, o);
+                IO::store_nt(dxb + (long)lo * C, o);
             }
         }
     }
@@ -372,130 +504,193 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
     }
 }
 
-// backward, wide kernel (any C): block per strip, threads own channels; no LDS reduction of partials needed.
-template <typename T, int VEC, int CH>
-__global__ __launch_bounds__(256) void dwconv7_ln_bwd_wide(const T* __restrict__ x, const T* __restrict__ dy,
-                                                          const T* __restrict__ dres, const float* __restrict__ w,
-                                                          const float* __restrict__ cb, const float* __restrict__ lw,
-                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          T* __restrict__ dx, float* __restrict__ partial,
-                                                          int B, int C, int L, int TL, int sps) {
-    __shared__ float red[2][4];
+// backward, wide kernel (C up to NT*4): one NT-thread workgroup per strip, a thread owns 4 channels; same row pipeline as
+// the strip kernel (register rings for x and dconv, QD packed rows of x / dy / dres in flight, no guarded loads).  The two
+// LayerNorm-backward row sums are independent of each other, so a group of R = 4 rows needs ONE barrier: per-wave sums
+// (DPP, wave-uniform) -> LDS -> 3 DPP steps over the first NW lanes.  mean/rstd of a row are uniform: scalar loads.
+template <typename T, int NT, int QD, bool HAS_RES>
+__global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         const T* __restrict__ dres, const float* __restrict__ w,
+                                                         const float* __restrict__ cb, const float* __restrict__ lw,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         T* __restrict__ dx, float* __restrict__ partial,
+                                                         int B, int C, int L, int TL, int sps) {
+    constexpr int VEC = 4, RING = 8, R = 2, NW = NT / 64;   // R = 2: a row's x window (7 rows) must still be in the 8-slot ring
+                                                              // when the group is finished (weight gradient)
+    static_assert(RING % QD == 0 && NW <= 8, "queue depth must divide the ring; at most 8 waves");
+    typedef VecIO<T, VEC> IO;
+    typedef typename IO::raw_t raw_t;
+    __shared__ __attribute__((aligned(16))) float red[2][NW][4];         // [parity of the group][wave][s1 row0, s1 row1, s2 row0, s2 row1]
     const int b = blockIdx.x / sps;
     const int l0 = (blockIdx.x % sps) * TL;
     const int l1 = min(l0 + TL, L);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rowbase = (long)b * L;
+    const int c = threadIdx.x * VEC;
+    const bool cok = c < C;
+    const int cidx = cok ? c : 0;                 // idle threads shadow chunk 0 (valid addresses), contribute nothing
+    // row addresses are uniform (scalar registers); the only per-thread part is the 32-bit channel offset cidx
     const T* xb = x + rowbase * C;
     const T* dyb = dy + rowbase * C;
+    const T* drb = HAS_RES ? dres + rowbase * C : nullptr;
     T* dxb = dx + rowbase * C;
+    const float* mub = mean + rowbase;
+    const float* rsb = rstd + rowbase;
     const float invC = 1.0f / (float)C;
-    int cidx[CH]; bool cok[CH];
-    float wt[CH][7][VEC], bias[CH][VEC], g[CH][VEC];
-    float pdw[CH][7][VEC], pdb[CH][VEC], pdg[CH][VEC], pdbeta[CH][VEC];
-    float dc[CH][7][VEC];          // dconv of rows l-6 .. l (slot = (row mod 7)), small TL so a plain shift is fine
+
+    float wt[7][VEC], bias[VEC], g[VEC];
 #pragma unroll
-    for (int k = 0; k < CH; k++) {
-        cidx[k] = (k * 256 + threadIdx.x) * VEC;
-        cok[k] = cidx[k] < C;
+    for (int v = 0; v < VEC; v++)
 #pragma unroll
-        for (int v = 0; v < VEC; v++) {
-            const int c = cok[k] ? cidx[k] + v : 0;
+        for (int t = 0; t < 7; t++) wt[t][v] = w[(cidx + v) * 7 + t];
+    IO_f4(cb + cidx, bias);
+    IO_f4(lw + cidx, g);
+    // The 10 parameter-gradient partial vectors of this thread's 4 channels live in LDS (thread-private float4 slots, no
+    // synchronisation): in registers (40 of them) the kernel exceeds 256 VGPRs at 8 waves per workgroup, and the spill
+    // reloads the compiler then places in the loop each wait for ALL outstanding loads (vmcnt(0)), undoing the prefetch.
+    extern __shared__ __attribute__((aligned(16))) float4 part[];        // [10][NT]: dw taps 0..6, db, dln_w, dln_b
+    auto padd = [&](int which, const float (&a)[VEC]) {
+        float4 t = part[which * NT + threadIdx.x];
+        t.x += a[0]; t.y += a[1]; t.z += a[2]; t.w += a[3];
+        part[which * NT + threadIdx.x] = t;
+    };
 #pragma unroll
-            for (int t = 0; t < 7; t++) { wt[k][t][v] = w[c * 7 + t]; pdw[k][t][v] = 0.f; dc[k][t][v] = 0.f; }
-            bias[k][v] = cb[c]; g[k][v] = lw[c];
-            pdb[k][v] = 0.f; pdg[k][v] = 0.f; pdbeta[k][v] = 0.f;
+    for (int j = 0; j < 10; j++) part[j * NT + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto clampl = [&](int l) -> long { return (long)min(max(l, 0), L - 1); };
+    auto enter = [&](raw_t r, bool pad, float (&dst)[VEC]) {
+        IO::unpack(r, dst);
+#pragma unroll
+        for (int v = 0; v < VEC; v++) dst[v] = pad ? 0.f : dst[v];
+    };
+    float xw[RING][VEC], dc[RING][VEC];
+    raw_t qx[QD], qdy[QD], qdr[QD];
+    float qmu[QD], qrs[QD];                      // uniform (scalar loads), fetched QD rows ahead like the rest
+    const int lw0 = l0 - 3;                      // first row of the walk
+    {
+        raw_t head[6];
+#pragma unroll
+        for (int s = 0; s < 6; s++) head[s] = IO::load_raw_nt(xb + clampl(lw0 - 3 + s) * C + cidx);
+#pragma unroll
+        for (int s = 0; s < QD; s++) {
+            qx[s] = IO::load_raw_nt(xb + clampl(lw0 + 3 + s) * C + cidx);
+            qdy[s] = IO::load_raw_nt(dyb + clampl(lw0 + s) * C + cidx);
+            qmu[s] = mub[clampl(lw0 + s)];
+            qrs[s] = rsb[clampl(lw0 + s)];
+            if (HAS_RES) qdr[s] = IO::load_raw_nt(drb + clampl(lw0 - 3 + s) * C + cidx);
         }
+#pragma unroll
+        for (int s = 0; s < 6; s++) { const int r = lw0 - 3 + s; enter(head[s], (r < 0) | (r >= L), xw[s]); }
     }
-    for (int l = l0 - 3; l < l1 + 3; l++) {
-        const bool inrow = (l >= 0 && l < L);
-        const bool own = (l >= l0 && l < l1);
-        float xh[CH][VEC], gg[CH][VEC], gy[CH][VEC], xr[CH][7][VEC];
-        float s1 = 0.f, s2 = 0.f;
-        float mu = 0.f, rs = 0.f;
-        if (inrow) { mu = mean[rowbase + l]; rs = rstd[rowbase + l]; }
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
+    for (int s = 0; s < RING; s++)
 #pragma unroll
-            for (int v = 0; v < VEC; v++) { xh[k][v] = 0.f; gg[k][v] = 0.f; gy[k][v] = 0.f; }
-            if (inrow && cok[k]) {
-                float a[VEC];
+        for (int v = 0; v < VEC; v++) dc[s][v] = 0.f;
+
+    const int lend = l1 + 3;
+    float gg[R][VEC], xh[R][VEC], ores[R][VEC], rsr[R];
+    int grp = 0;
+    for (int base = lw0; base < lend; base += RING) {
 #pragma unroll
-                for (int v = 0; v < VEC; v++) a[v] = bias[k][v];
+        for (int i = 0; i < RING; i++) {
+            const int l = base + i;
+            const int r = i % R, k = i % QD;
+            enter(qx[k], (l + 3 < 0) | (l + 3 >= L), xw[(i + 6) % RING]);
+            qx[k] = IO::load_raw_nt(xb + clampl(l + 3 + QD) * C + cidx);
+            const bool inrow = (l >= 0) & (l < L) & (l < lend);          // uniform
+            float gy[VEC];
+            enter(qdy[k], !inrow, gy);
+            qdy[k] = IO::load_raw_nt(dyb + clampl(l + QD) * C + cidx);
+            if (HAS_RES) {
+                IO::unpack(qdr[k], ores[r]);                             // dres of row l-3 (used if that row is ours)
+                qdr[k] = IO::load_raw_nt(drb + clampl(l - 3 + QD) * C + cidx);
+            } else {
 #pragma unroll
-                for (int t = 0; t < 7; t++) {
-                    const int ll = l + t - 3;
-                    if (ll >= 0 && ll < L) VecIO<T, VEC>::load(xb + (long)ll * C + cidx[k], xr[k][t]);
-                    else {
-#pragma unroll
-                        for (int v = 0; v < VEC; v++) xr[k][t][v] = 0.f;
-                    }
-#pragma unroll
-                    for (int v = 0; v < VEC; v++) a[v] = fmaf(wt[k][t][v], xr[k][t][v], a[v]);
-                }
-                VecIO<T, VEC>::load(dyb + (long)l * C + cidx[k], gy[k]);
-#pragma unroll
-                for (int v = 0; v < VEC; v++) {
-                    xh[k][v] = (a[v] - mu) * rs;
-                    gg[k][v] = gy[k][v] * g[k][v];
-                    s1 += gg[k][v]; s2 = fmaf(gg[k][v], xh[k][v], s2);
-                }
+                for (int v = 0; v < VEC; v++) ores[r][v] = 0.f;
             }
-        }
-        const float m1 = block_sum<4>(s1, red[0]) * invC;
-        const float m2 = block_sum<4>(s2, red[1]) * invC;
-#pragma unroll
-        for (int k = 0; k < CH; k++) {
-            // shift the dconv history: slot t holds dconv(l - t) after this update
-#pragma unroll
-            for (int t = 6; t > 0; t--)
-#pragma unroll
-                for (int v = 0; v < VEC; v++) dc[k][t][v] = dc[k][t - 1][v];
-#pragma unroll
-            for (int v = 0; v < VEC; v++)
-                dc[k][0][v] = (inrow && cok[k]) ? rs * (gg[k][v] - m1 - xh[k][v] * m2) : 0.f;
-            if (own && cok[k]) {
-#pragma unroll
-                for (int v = 0; v < VEC; v++) {
-                    pdg[k][v] = fmaf(gy[k][v], xh[k][v], pdg[k][v]);
-                    pdbeta[k][v] += gy[k][v];
-                    pdb[k][v] += dc[k][0][v];
-#pragma unroll
-                    for (int t = 0; t < 7; t++) pdw[k][t][v] = fmaf(dc[k][0][v], xr[k][t][v], pdw[k][t][v]);
-                }
-            }
-            const int lo = l - 3;
-            if (lo >= l0 && lo < l1 && cok[k]) {
-                float o[VEC];
-                if (dres) VecIO<T, VEC>::load(dres + (rowbase + lo) * C + cidx[k], o);
-                else {
-#pragma unroll
-                    for (int v = 0; v < VEC; v++) o[v] = 0.f;
-                }
-#pragma unroll
-                for (int v = 0; v < VEC; v++) {
-                    float a = o[v];
-#pragma unroll
-                    for (int t = 0; t < 7; t++) a = fmaf(wt[k][t][v], dc[k][t][v], a);
-                    o[v] = a;
-                }
-                VecIO<T, VEC>::store(dxb + (long)lo * C + cidx[k], o);
-            }
-        }
-    }
-    float* prow = partial + (long)blockIdx.x * 10 * C;
-#pragma unroll
-    for (int k = 0; k < CH; k++)
-        if (cok[k]) {
+            __builtin_amdgcn_sched_barrier(0);    // keep the loads here: the scheduler would sink them to their use
+            const float mu = inrow ? qmu[k] : 0.f;
+            const float rs = inrow ? qrs[k] : 0.f;
+            qmu[k] = mub[clampl(l + QD)];                                // uniform address: scalar loads
+            qrs[k] = rsb[clampl(l + QD)];
+            rsr[r] = rs;
+            const bool own = (l >= l0) & (l < l1);
 #pragma unroll
             for (int v = 0; v < VEC; v++) {
-                const int c = cidx[k] + v;
+                float a = bias[v];
 #pragma unroll
-                for (int t = 0; t < 7; t++) prow[t * C + c] = pdw[k][t][v];
-                prow[7 * C + c] = pdb[k][v];
-                prow[8 * C + c] = pdg[k][v];
-                prow[9 * C + c] = pdbeta[k][v];
+                for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], xw[(i + t) % RING][v], a);
+                xh[r][v] = (a - mu) * rs;
+                gg[r][v] = gy[v] * g[v];
+            }
+            if (own) {                                                   // uniform
+                float t8[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; v++) t8[v] = gy[v] * xh[r][v];
+                padd(8, t8);
+                padd(9, gy);
+            }
+            if (r != R - 1) continue;
+            // ---- the group's 2 rows: both row sums with one barrier
+            float s1[R], s2[R];
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int v = 0; v < VEC; v++) { t1 += gg[rr][v]; t2 = fmaf(gg[rr][v], xh[rr][v], t2); }
+                s1[rr] = wave_sum_u(cok ? t1 : 0.f);
+                s2[rr] = wave_sum_u(cok ? t2 : 0.f);
+            }
+            const int par = grp & 1;
+            grp++;
+            if (lane == 0) *reinterpret_cast<float4*>(red[par][wave]) = make_float4(s1[0], s1[1], s2[0], s2[1]);
+            __syncthreads();
+            float4 ps = *reinterpret_cast<const float4*>(red[par][lane < NW ? lane : 0]);
+            if (lane >= NW) ps = make_float4(0.f, 0.f, 0.f, 0.f);
+            float m1[R], m2[R];
+            m1[0] = first8_sum_u(ps.x) * invC; m1[1] = first8_sum_u(ps.y) * invC;
+            m2[0] = first8_sum_u(ps.z) * invC; m2[1] = first8_sum_u(ps.w) * invC;
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) {
+                const int ii = i - (R - 1) + rr;            // unroll index of this row (static)
+                const int lr = l - (R - 1) + rr;
+                const bool ownr = (lr >= l0) & (lr < l1);
+                float d[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; v++) {
+                    d[v] = cok ? rsr[rr] * (gg[rr][v] - m1[rr] - xh[rr][v] * m2[rr]) : 0.f;
+                    dc[ii][v] = d[v];                       // dconv ring slot of row lr is ii (RING == unroll)
+                }
+                if (ownr) {                                 // uniform
+                    padd(7, d);
+#pragma unroll
+                    for (int t = 0; t < 7; t++) {
+                        float pw[VEC];
+#pragma unroll
+                        for (int v = 0; v < VEC; v++) pw[v] = d[v] * xw[(ii + t) % RING][v];
+                        padd(t, pw);
+                    }
+                }
+                // dx(lr-3) = sum_t w[t] * dconv(lr-t)
+                const int lo = lr - 3;
+                if (cok && lo >= l0 && lo < l1) {
+                    float o[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) {
+                        float a = ores[rr][v];
+#pragma unroll
+                        for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], dc[(ii - t + RING) % RING][v], a);
+                        o[v] = a;
+                    }
+                    IO::store_nt(dxb + (long)lo * C + cidx, o);
+                }
             }
         }
+    }
+    if (cok) {
+        float* prow = partial + (long)blockIdx.x * 10 * C;
+#pragma unroll
+        for (int j = 0; j < 10; j++) *reinterpret_cast<float4*>(prow + j * C + c) = part[j * NT + threadIdx.x];
+    }
 }
 
 // second stage: fixed-order sum over workspace rows; writes dw[C][7], db, dln_w, dln_b
@@ -537,8 +732,10 @@ static int launch_fwd_strip(const void* x, const float* w, const float* b, const
     const int sps = (int)cdiv(L, TL);
     const int64_t waves = cdiv(B * sps, spw);
     const dim3 grid((unsigned)cdiv(waves, 4));
-#define LAUNCH_(LPR_) hipLaunchKernelGGL((dwconv7_ln_fwd_strip<T, VEC, LPR_>), grid, dim3(256), 0, st, (const T*)x, w, b, lw, lb, \
-                                         (T*)y, mean, rstd, (int)B, (int)L, TL, sps, eps)
+    static int qd = getenv("MM_K1_QD") ? atoi(getenv("MM_K1_QD")) : (sizeof(T) == 2 ? 8 : 4);   // rows in flight per strip (measured best)
+#define LAUNCH_Q(LPR_, QD_) hipLaunchKernelGGL((dwconv7_ln_fwd_strip<T, VEC, LPR_, QD_>), grid, dim3(256), 0, st, (const T*)x, w, b, \
+                                               lw, lb, (T*)y, mean, rstd, (int)B, (int)L, TL, sps, eps)
+#define LAUNCH_(LPR_) do { if (qd == 2) LAUNCH_Q(LPR_, 2); else if (qd == 8) LAUNCH_Q(LPR_, 8); else LAUNCH_Q(LPR_, 4); } while (0)
     switch (lpr) {
         case 8: LAUNCH_(8); break;
         case 16: LAUNCH_(16); break;
@@ -547,6 +744,7 @@ static int launch_fwd_strip(const void* x, const float* w, const float* b, const
         default: MM_FAIL(MM_ERR_UNSUPPORTED, "dwconv7_ln strip kernel: C/VEC=%d unsupported", lpr);
     }
 #undef LAUNCH_
+#undef LAUNCH_Q
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
@@ -554,16 +752,20 @@ static int launch_fwd_strip(const void* x, const float* w, const float* b, const
 template <typename T>
 static int launch_fwd_wide(const void* x, const float* w, const float* b, const float* lw, const float* lb, void* y,
                            float* mean, float* rstd, int64_t B, int64_t C, int64_t L, float eps, hipStream_t st) {
-    const int TL = pick_tl(B, L, 1, 1, 16);
+    MM_CHECK(C % 4 == 0 && C <= 4096, "dwconv7_ln: C=%lld unsupported (need C %% 4 == 0 and C <= 4096)", (long long)C);
+    // whole samples per workgroup when the batch alone fills the chip (no halo rows at all), shorter strips otherwise
+    const int TL = pick_tl(B, L, 1, 4, 64);
     const int sps = (int)cdiv(L, TL);
     const dim3 grid((unsigned)(B * sps));
-#define LAUNCH_(VEC_, CH_) hipLaunchKernelGGL((dwconv7_ln_fwd_wide<T, VEC_, CH_>), grid, dim3(256), 0, st, (const T*)x, w, b, lw, \
-                                              lb, (T*)y, mean, rstd, (int)B, (int)C, (int)L, TL, sps, eps)
-    if (C % 4 == 0 && C <= 1024) LAUNCH_(4, 1);
-    else if (C % 4 == 0 && C <= 2048) LAUNCH_(4, 2);
-    else if (C % 4 == 0 && C <= 4096) LAUNCH_(4, 4);
-    else if (C <= 1024) LAUNCH_(1, 4);
-    else MM_FAIL(MM_ERR_UNSUPPORTED, "dwconv7_ln: C=%lld unsupported (need C%%4==0 and C<=4096, or C<=1024)", (long long)C);
+#define LAUNCH_(NT_, CH_, QD_) hipLaunchKernelGGL((dwconv7_ln_fwd_wide<T, NT_, CH_, QD_>), grid, dim3(NT_), 0, st, (const T*)x, w, b, \
+                                                  lw, lb, (T*)y, mean, rstd, (int)B, (int)C, (int)L, TL, sps, eps)
+    static int variant = getenv("MM_K1W_VARIANT") ? atoi(getenv("MM_K1W_VARIANT")) : 0;      // A/B knob
+    if (C <= 1024) { if (variant == 1) LAUNCH_(256, 1, 8); else LAUNCH_(256, 1, 4); }
+    else if (C <= 2048) {
+        if (variant == 1) LAUNCH_(512, 1, 8);
+        else if (variant == 2) LAUNCH_(256, 2, 4);
+        else LAUNCH_(512, 1, 4);
+    } else LAUNCH_(512, 2, 2);
 #undef LAUNCH_
     MM_LAUNCH_CHECK();
     return MM_OK;
@@ -629,7 +831,7 @@ static BwdPlan plan_bwd(int64_t B, int64_t C, int64_t L, int dtype) {
         p.nblocks = cdiv(cdiv(B * p.sps, spw), 4);
     } else {
         p.strip = false;
-        p.TL = pick_tl(B, L, 1, 4, 32);
+        p.TL = pick_tl(B, L, 1, 8, 64);
         p.sps = (int)cdiv(L, p.TL);
         p.nblocks = B * p.sps;
     }
@@ -649,8 +851,12 @@ static int launch_bwd(const BwdPlan& p, const void* x, const void* dy, const voi
                       int64_t C, int64_t L, hipStream_t st) {
     const dim3 grid((unsigned)p.nblocks);
     if (p.strip) {
-#define LAUNCH_(LPR_) hipLaunchKernelGGL((dwconv7_ln_bwd_strip<T, 4, LPR_>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, \
-                                         (const T*)dres, w, b, lw, mean, rstd, (T*)dx, partial, (int)B, (int)L, p.TL, p.sps)
+        static int qd = getenv("MM_K1B_QD") ? atoi(getenv("MM_K1B_QD")) : 2;     // rows in flight per tensor per strip (4: one wave per SIMD, slower)
+#define LAUNCH_Q(LPR_, QD_, RES_) hipLaunchKernelGGL((dwconv7_ln_bwd_strip<T, 4, LPR_, QD_, RES_>), grid, dim3(256), 0, st, (const T*)x, \
+                                                     (const T*)dy, (const T*)dres, w, b, lw, mean, rstd, (T*)dx, partial, (int)B, (int)L, \
+                                                     p.TL, p.sps)
+#define LAUNCH_(LPR_) do { if (dres) { if (qd == 2) LAUNCH_Q(LPR_, 2, true); else LAUNCH_Q(LPR_, 4, true); } \
+                           else { if (qd == 2) LAUNCH_Q(LPR_, 2, false); else LAUNCH_Q(LPR_, 4, false); } } while (0)
         switch (p.lpr) {
             case 16: LAUNCH_(16); break;
             case 32: LAUNCH_(32); break;
@@ -658,15 +864,18 @@ static int launch_bwd(const BwdPlan& p, const void* x, const void* dy, const voi
             default: MM_FAIL(MM_ERR_UNSUPPORTED, "dwconv7_ln_bwd: lpr=%d", p.lpr);
         }
 #undef LAUNCH_
+#undef LAUNCH_Q
     } else {
-#define LAUNCH_(VEC_, CH_) hipLaunchKernelGGL((dwconv7_ln_bwd_wide<T, VEC_, CH_>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, \
-                                              (const T*)dres, w, b, lw, mean, rstd, (T*)dx, partial, (int)B, (int)C, (int)L, p.TL, p.sps)
-        if (C % 4 == 0 && C <= 1024) LAUNCH_(4, 1);
-        else if (C % 4 == 0 && C <= 2048) LAUNCH_(4, 2);
-        else if (C <= 256) LAUNCH_(1, 1);
-        else if (C <= 512) LAUNCH_(1, 2);
-        else MM_FAIL(MM_ERR_UNSUPPORTED, "dwconv7_ln_bwd: C=%lld unsupported (need C%%4==0 and C<=2048, or C<=512)", (long long)C);
-#undef LAUNCH_
+        MM_CHECK(C % 4 == 0 && C <= 2048, "dwconv7_ln_bwd: C=%lld unsupported (need C %% 4 == 0 and C <= 2048)", (long long)C);
+#define LAUNCH_W(NT_, RES_) do { \
+            const size_t lds_ = (size_t)10 * NT_ * sizeof(float4); \
+            static bool attr_ = false;                 /* 80 KiB at NT = 512: above the default dynamic-LDS limit */ \
+            if (!attr_) { (void)hipFuncSetAttribute((const void*)dwconv7_ln_bwd_wide<T, NT_, 2, RES_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); attr_ = true; } \
+            hipLaunchKernelGGL((dwconv7_ln_bwd_wide<T, NT_, 2, RES_>), grid, dim3(NT_), lds_, st, (const T*)x, (const T*)dy, \
+                               (const T*)dres, w, b, lw, mean, rstd, (T*)dx, partial, (int)B, (int)C, (int)L, p.TL, p.sps); } while (0)
+        if (C <= 1024) { if (dres) LAUNCH_W(256, true); else LAUNCH_W(256, false); }
+        else { if (dres) LAUNCH_W(512, true); else LAUNCH_W(512, false); }
+#undef LAUNCH_W
     }
     MM_LAUNCH_CHECK();
     return MM_OK;

@@ -54,3 +54,32 @@ def rel_err(a, b):
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def elem_err(a, b):
+    """Elementwise companion of rel_err (a max-norm measure lets an element near zero be 100 % wrong): the largest
+    |a - b| / (|b| + rms(b)) over all elements.  `elem_err(a, b) < tol` is `|a-b| <= tol * (|b| + rms(b))` everywhere."""
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    rms = b.pow(2).mean().sqrt().clamp_min(1e-30)
+    return float(((a - b).abs() / (b.abs() + rms)).max())
+
+
+@pytest.fixture(scope="session")
+def config_meta():
+    with open(os.path.join(GOLDEN, "meta_config.json")) as fh:
+        return json.load(fh)
+
+
+def check_grads_against_golden(grads, g, tol, name=""):
+    """grads: {parameter name: gradient tensor}; g: a golden npz dict with 'grad.<name>' entries (nmr_embed by rows)."""
+    n = 0
+    for k, v in g.items():
+        if not k.startswith("grad.") or k == "grad.ir" or k.endswith(".rows"):
+            continue
+        got = grads[k[5:]].detach().float().cpu()
+        if k + ".rows" in g:
+            got = got[torch.from_numpy(g[k + ".rows"])]
+        assert rel_err(got, v) < tol, (name, k, rel_err(got, v))
+        n += 1
+    return n

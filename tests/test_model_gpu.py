@@ -7,7 +7,7 @@ import os
 import pytest
 import torch
 
-from conftest import GOLDEN, case_inputs, cfg_of, load_golden, rel_err
+from conftest import GOLDEN, case_inputs, cfg_of, elem_err, load_golden, rel_err
 from oracle import fill, restate
 from oracle.shapes import formula_state_dict
 
@@ -49,8 +49,13 @@ def test_forward_fp32_vs_reference_golden(golden_meta, name):
     with torch.no_grad():
         mem = m.encoder(None, ir.to(DEV), None)
         logits = m(nmr.to(DEV), ir.to(DEV), tgt[:, :-1].to(DEV), None)
-    assert rel_err(mem[:2].float().cpu(), g["memory"]) < 1e-4
-    assert rel_err(logits.cpu(), g["logits"]) < 1e-4
+    assert rel_err(mem[:2].float().cpu(), g["memory"]) < 1e-4 and elem_err(mem[:2].float().cpu(), g["memory"]) < 1e-4
+    assert rel_err(logits.cpu(), g["logits"]) < 1e-4 and elem_err(logits.cpu(), g["logits"]) < 1e-4
+
+
+# north_star's bf16 bar is 2e-2 on encoder/attention outputs; the logits behind L decoder layers are held to it too
+# (achieved 0.7-1.2e-2 here, 1.1-1.3e-2 at the config shapes in tests/test_config_gpu.py).
+BF16_LOGITS_TOL = {"tiny_sm": 2e-2, "d100_sm": 2e-2, "d128_sdpa": 2e-2, "d192_sm": 2e-2, "d512_sm": 2e-2}
 
 
 @pytest.mark.parametrize("name", ["tiny_sm", "d100_sm", "d128_sdpa", "d192_sm", "d512_sm"])
@@ -62,8 +67,10 @@ def test_forward_bf16_vs_reference_golden(golden_meta, name):
     with torch.no_grad():
         mem = m.encoder(None, ir.to(DEV), None)
         logits = m(nmr.to(DEV), ir.to(DEV), tgt[:, :-1].to(DEV), None)
+    if os.environ.get("MM_TEST_REPORT"):
+        print(name, "bf16 memory", rel_err(mem[:2].float().cpu(), g["memory"]), "logits", rel_err(logits.cpu(), g["logits"]), flush=True)
     assert rel_err(mem[:2].float().cpu(), g["memory"]) < 2e-2
-    assert rel_err(logits.cpu(), g["logits"]) < 5e-2       # 2e-2 per op; the logits sit behind L decoder layers
+    assert rel_err(logits.cpu(), g["logits"]) < BF16_LOGITS_TOL[name]
 
 
 @pytest.mark.parametrize("name", ["tiny_sm", "d100_sm", "d128_sdpa"])
