@@ -7,10 +7,10 @@ LayerNorm -> fused QKV projection (M = batch rows) -> K4 (rotate, append to cach
 MLP.  Batch-sharded across GPUs with no collective: each rank owns its rows and its cache."""
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
-import torch.nn.functional as F
 
 from . import functional as FN
 from . import ops
@@ -24,12 +24,37 @@ class KVCache:
 
 
 def _layer_weights(layer, dt):
+    """GEMM operands of one layer from the operand cache (functional.cached_operand: built once per parameter version,
+    refreshed by the optimizer -- nothing is re-cast or re-concatenated per generate() call).  Weights in the compute
+    dtype, biases as float32 (the libmmhip epilogues add them to the float32 accumulator)."""
+    co = FN.cached_operand
     return dict(
-        wqkv=torch.cat((layer.q.weight, layer.k.weight, layer.v.weight), 0).to(dt).contiguous(),
-        bqkv=torch.cat((layer.q.bias, layer.k.bias, layer.v.bias), 0).to(dt).contiguous(),
-        wo=layer.out.weight.to(dt), bo=layer.out.bias.to(dt),
-        w1=layer.ffn_w1.weight.to(dt), b1=layer.ffn_w1.bias.to(dt),
-        w2=layer.ffn_w2.weight.to(dt), b2=layer.ffn_w2.bias.to(dt))
+        wqkv=co((layer.q.weight, layer.k.weight, layer.v.weight), dt),
+        bqkv=co((layer.q.bias, layer.k.bias, layer.v.bias), torch.float32),
+        bqkv16=co((layer.q.bias, layer.k.bias, layer.v.bias), dt),
+        wo=co((layer.out.weight,), dt), bo=layer.out.bias.detach(),
+        w1=co((layer.ffn_w1.weight,), dt), b1=layer.ffn_w1.bias.detach(), b116=co((layer.ffn_w1.bias,), dt),
+        w2=co((layer.ffn_w2.weight,), dt), b2=layer.ffn_w2.bias.detach(), b216=co((layer.ffn_w2.bias,), dt))
+
+
+_DECODE_GEMM = os.environ.get("MM_DECODE_GEMM", "auto")    # A/B knob: "mm" = every product on libmmhip, "lib" = none
+
+
+def _lin(x2, w, b, b16=None, act=0, res=None, out_dtype=None, square=False):
+    """x2 [M,K] @ w[N,K]^T + b (+ relu^2) (+ res).  At decode shapes (M = batch rows, about 1000) the products are short
+    and latency-bound; measured on MI355X (bf16, M = 1024): the libmmhip GEMM with its fused bias + residual epilogue wins
+    for the square E x E product (13.0 vs 15.0 us), the library wins for N = 3E / 4E and K = 4E (13.5-21.5 vs 22-45 us),
+    so those run there with the bias in the library's epilogue and relu^2 / the residual as one libmmhip / in-place pass.
+    b is the float32 bias (libmmhip epilogue), b16 its compute-dtype copy from the operand cache (library epilogue)."""
+    use_mm = _DECODE_GEMM == "mm" or (_DECODE_GEMM == "auto" and square and x2.dtype == torch.bfloat16)
+    if use_mm:
+        return ops.gemm(x2, w, x2.shape[0], w.shape[0], w.shape[1], bias=b, act=act, res=res, out_dtype=out_dtype)
+    y = torch.addmm(b16 if b16 is not None else b.to(x2.dtype), x2, w.t())
+    if act == ops.ACT_RELU2:
+        y = ops.relu2_fwd(y)
+    if res is not None:
+        y.add_(res)
+    return y if out_dtype in (None, y.dtype) else y.to(out_dtype)
 
 
 @torch.no_grad()
@@ -59,7 +84,8 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
         steps = Smax - P
     cache = KVCache(len(dec.layers), B, H, Smax, d, dt, dev)
     weights = [_layer_weights(l, dt) for l in dec.layers]
-    w_out, b_out = dec.out.weight.to(dt), dec.out.bias.to(dt)
+    w_out, b_out = FN.cached_operand((dec.out.weight,), dt), dec.out.bias.detach()
+    b_out16 = FN.cached_operand((dec.out.bias,), dt)
     emb = dec.smiles_embed.weight
 
     tokens = torch.full((B, steps + 1), bos_id, dtype=torch.long, device=dev)
@@ -69,16 +95,20 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
     for li, layer in enumerate(dec.layers):
         w = weights[li]
         cos_t, sin_t = layer.rotary_emb.half_tables(Smax)
+        M0 = B * S0
         xa, _, _ = ops.layernorm_fwd(x, layer.attn_norm.weight, layer.attn_norm.bias)
-        qkv = F.linear(xa, w["wqkv"], w["bqkv"]).view(B, S0, 3, E)
+        # the big prefill products stay on the library where it wins (N = 3E, 4E: DESIGN.md 4), the N = E products with
+        # their bias + residual run on the large-tile kernel, as in the training forward
+        qkv = torch.addmm(w["bqkv16"], xa.view(M0, E), w["wqkv"].t()).view(B, S0, 3, E)
         ops.kv_cache_fill(qkv[:, :, 1], qkv[:, :, 2], cache.k[li], cache.v[li], H, layer.rotary_ndims, cos_t, sin_t)
         a, _ = ops.prefix_attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], H, layer.rotary_ndims, P, cos_t, sin_t,
                                    layer.use_stablemax)
-        x = F.linear(a, w["wo"], w["bo"]) + x
+        x = _lin(a.view(M0, E), w["wo"], w["bo"], res=x.view(M0, E), square=True).view(B, S0, E)
         xf, _, _ = ops.layernorm_fwd(x, layer.mlp_norm.weight, layer.mlp_norm.bias)
-        x = x + F.linear(F.relu(F.linear(xf, w["w1"], w["b1"])).square(), w["w2"], w["b2"])
+        u = ops.relu2_fwd(torch.addmm(w["b116"], xf.view(M0, E), w["w1"].t()))
+        x = _lin(u, w["w2"], w["b2"], res=x.view(M0, E), square=True).view(B, S0, E)      # prefill: N = E on the large-tile kernel
     xt, _, _ = ops.layernorm_fwd(x[:, -1].contiguous(), dec.final_norm.weight, dec.final_norm.bias)
-    nxt = ops.argmax_rows(F.linear(xt, w_out, b_out).float())                  # :102
+    nxt = ops.argmax_rows(_lin(xt, w_out, b_out, b_out16, out_dtype=torch.float32))     # :102
     tokens[:, 1] = nxt
     finished = nxt == eos_id
     n_done = 1
@@ -89,15 +119,18 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
         for li, layer in enumerate(dec.layers):
             w = weights[li]
             cos_t, sin_t = layer.rotary_emb.half_tables(Smax)
+            # LN, QKV (+bias), K4, out-proj (+bias +residual fused), LN, W1 (+bias) relu^2, W2 (+bias) += residual; operands
+            # and bias copies come from the operand cache (no per-call casts)
             xa, _, _ = ops.layernorm_fwd(h, layer.attn_norm.weight, layer.attn_norm.bias)
-            qkv = F.linear(xa, w["wqkv"], w["bqkv"])                           # [B, 3E]
+            qkv = _lin(xa, w["wqkv"], w["bqkv"], w["bqkv16"])                  # [B, 3E]
             a = ops.decode_attn(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cache.k[li], cache.v[li], H,
                                 layer.rotary_ndims, pos, cos_t, sin_t, layer.use_stablemax)
-            h = F.linear(a, w["wo"], w["bo"]) + h
+            h = _lin(a, w["wo"], w["bo"], res=h, square=True)
             xf, _, _ = ops.layernorm_fwd(h, layer.mlp_norm.weight, layer.mlp_norm.bias)
-            h = h + F.linear(F.relu(F.linear(xf, w["w1"], w["b1"])).square(), w["w2"], w["b2"])
+            u = _lin(xf, w["w1"], w["b1"], w["b116"], act=ops.ACT_RELU2)
+            h = _lin(u, w["w2"], w["b2"], w["b216"], res=h)
         xt, _, _ = ops.layernorm_fwd(h, dec.final_norm.weight, dec.final_norm.bias)
-        return ops.argmax_rows(F.linear(xt, w_out, b_out).float())
+        return ops.argmax_rows(_lin(xt, w_out, b_out, b_out16, out_dtype=torch.float32))
 
     use_graph = bool(graph)
     if use_graph and steps > 2:
