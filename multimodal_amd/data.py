@@ -1,0 +1,247 @@
+"""Input pipeline of the hot path's caller: the reference's SpectralSmilesDataset + collate_fn
+(train_autoregressive.py:232-411) with the same file formats and the same batches, rebuilt so that 8 GPUs are not
+starved by per-sample Python work:
+
+  files   src-{split}.txt   whitespace-separated NMR tokens, one sample per line          (:257-258)
+          tgt-{split}.txt   SMILES, spaces removed on load                                 (:259-261)
+          ir-{split}.npy    RAW float32 [num_samples, feature_dim], no .npy header -- written by np.memmap(mode='w+')
+                            (create_tokenized_dataset_faster.py:278), read back flat and reshaped (:269-282)
+          ../vocab.json     NMR vocabulary token -> id with "<PAD>" and "<UNK>"            (:414-438)
+
+* `SpectralSmilesDataset` / `collate_fn` keep the reference's signatures and return values (drop-in for its DataLoader).
+* `TokenizedSplit` tokenises a split ONCE into flat int32 arrays + offsets (the reference re-tokenises every sample
+  on every access, with num_workers=0).
+* `PinnedBatchLoader` assembles whole batches with numpy slicing into a ring of pinned host buffers on a prefetch
+  thread and copies them to the device on a copy stream: the train loop only waits on an event.  The batches equal
+  collate_fn's (ids, padding values, dynamic padded widths) for the same sample order; on a DP rank it serves that
+  rank's contiguous slice of every global batch.
+No GPU arithmetic happens here; integer / byte exactness is by construction and tested against oracle/restate_data.py
+(PARITY UNPINNED: the reference module needs wandb/rdkit to import and ships no fixtures for this path)."""
+from __future__ import annotations
+
+import json
+import queue
+import threading
+from pathlib import Path
+from typing import Dict, Iterator, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def load_vocabularies(tokenized_dir, smiles_tokenizer):
+    """train_autoregressive.py:414-438: NMR vocab.json sits next to tokenized_dir; sizes = (len(tokenizer), max id + 1)."""
+    path = Path(tokenized_dir).parent / "vocab.json"
+    if not path.exists():
+        raise FileNotFoundError(f"NMR vocabulary not found at {path}")
+    with open(path) as fh:
+        nmr_tokenizer = json.load(fh)
+    return len(smiles_tokenizer), max(nmr_tokenizer.values()) + 1, nmr_tokenizer
+
+
+def _open_ir(data_dir: Path, split: str, num_samples: int):
+    path = data_dir / f"ir-{split}.npy"
+    if not path.exists() or num_samples == 0:
+        return None
+    flat = np.memmap(path, dtype="float32", mode="r")             # raw floats: the file has no .npy header
+    if flat.shape[0] % num_samples:
+        raise ValueError(f"{path}: {flat.shape[0]} floats do not divide into {num_samples} samples")
+    return flat.reshape(num_samples, flat.shape[0] // num_samples)
+
+
+class SpectralSmilesDataset(torch.utils.data.Dataset):
+    """Same constructor, __len__ and __getitem__ as the reference class (train_autoregressive.py:232-361):
+    item = (target_tokens int64 [T], (ir float32 [F] | None, None), nmr_tokens int64 [N], None)."""
+
+    def __init__(self, data_dir, smiles_tokenizer, spectral_tokenizer, split="train", max_smiles_len=512, max_nmr_len=128):
+        super().__init__()
+        self.data_dir = Path(data_dir)
+        self.smiles_tokenizer = smiles_tokenizer
+        self.spectral_tokenizer = spectral_tokenizer
+        self.max_smiles_len = max_smiles_len
+        self.max_nmr_len = max_nmr_len
+        self.split = split
+        with open(self.data_dir / f"src-{split}.txt") as fh:
+            self.sources = [line.strip() for line in fh]
+        with open(self.data_dir / f"tgt-{split}.txt") as fh:
+            self.targets = [line.strip().replace(" ", "") for line in fh]
+        self.ir_data = _open_ir(self.data_dir, split, len(self.sources))
+
+    def __len__(self):
+        return len(self.sources)
+
+    def encode_target(self, idx: int) -> List[int]:
+        return self.smiles_tokenizer.encode(self.targets[idx], add_special_tokens=True, max_length=self.max_smiles_len,
+                                            truncation=True)
+
+    def encode_source(self, idx: int) -> List[int]:
+        unk = self.spectral_tokenizer["<UNK>"]
+        return [self.spectral_tokenizer.get(tok, unk) for tok in self.sources[idx].split()][: self.max_nmr_len]
+
+    def __getitem__(self, idx):
+        ir = None
+        if self.ir_data is not None:
+            ir = torch.from_numpy(np.array(self.ir_data[idx], dtype=np.float32))
+        return (torch.tensor(self.encode_target(idx), dtype=torch.long), (ir, None),
+                torch.tensor(self.encode_source(idx), dtype=torch.long), None)
+
+
+def collate_fn(batch, spectral_tokenizer, pad_token_id: int = 0):
+    """train_autoregressive.py:372-411: right-pad targets with the SMILES [PAD] id (0) and NMR tokens with
+    spectral_tokenizer["<PAD>"] to the longest of the batch, stack IR -> (target [B,T], ir [B,F] | None, nmr [B,N], None)."""
+    targets, ir_tuples, nmrs, _ = zip(*batch)
+
+    def pad(seqs, value):
+        width = max(len(s) for s in seqs)
+        out = torch.full((len(seqs), width), value, dtype=torch.long)
+        for i, s in enumerate(seqs):
+            out[i, : len(s)] = s
+        return out
+
+    ir = [t[0] for t in ir_tuples if t[0] is not None]
+    return pad(targets, pad_token_id), (torch.stack(ir, 0) if ir else None), pad(nmrs, spectral_tokenizer["<PAD>"]), None
+
+
+class TokenizedSplit:
+    """A split tokenised once: flat int32 id arrays + int64 offsets for targets and NMR tokens, and the IR memmap."""
+
+    def __init__(self, dataset: SpectralSmilesDataset):
+        n = len(dataset)
+        self.n = n
+        self.nmr_pad = int(dataset.spectral_tokenizer["<PAD>"])
+        self.tgt_pad = int(getattr(dataset.smiles_tokenizer, "pad_token_id", 0))
+        tgt = [dataset.encode_target(i) for i in range(n)]
+        src = [dataset.encode_source(i) for i in range(n)]
+        self.tgt_off = np.zeros(n + 1, dtype=np.int64)
+        self.src_off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(t) for t in tgt], out=self.tgt_off[1:])
+        np.cumsum([len(s) for s in src], out=self.src_off[1:])
+        self.tgt_ids = np.fromiter((v for t in tgt for v in t), dtype=np.int32, count=int(self.tgt_off[-1]))
+        self.src_ids = np.fromiter((v for s in src for v in s), dtype=np.int32, count=int(self.src_off[-1]))
+        self.ir = dataset.ir_data
+
+    def fill(self, idx: Sequence[int], tgt_out: np.ndarray, nmr_out: np.ndarray, ir_out: Optional[np.ndarray]):
+        """Write the batch `idx` into preallocated int64 [B, >=width] / float32 [B, F] host arrays; returns the padded
+        widths (longest target, longest NMR sequence of the batch -- collate_fn's dynamic padding)."""
+        tl = self.tgt_off[np.asarray(idx) + 1] - self.tgt_off[np.asarray(idx)]
+        sl = self.src_off[np.asarray(idx) + 1] - self.src_off[np.asarray(idx)]
+        tw, sw = int(tl.max()), int(sl.max())
+        tgt_out[: len(idx), :tw] = self.tgt_pad
+        nmr_out[: len(idx), :sw] = self.nmr_pad
+        for r, i in enumerate(idx):
+            tgt_out[r, : tl[r]] = self.tgt_ids[self.tgt_off[i]: self.tgt_off[i + 1]]
+            nmr_out[r, : sl[r]] = self.src_ids[self.src_off[i]: self.src_off[i + 1]]
+        if ir_out is not None:
+            order = np.argsort(idx, kind="stable")                # ascending file offsets: sequential page reads
+            ir_out[order] = self.ir[np.asarray(idx)[order]]
+        return tw, sw
+
+
+class PinnedBatchLoader:
+    """Iterates (target [B,T], ir [B,F] | None, nmr [B,N], None) device tensors, equal to
+    DataLoader(dataset, batch_size, shuffle, collate_fn) batches for the same sample order.
+
+    order:  per epoch a permutation from `torch.randperm(n, generator=seed + epoch)` when shuffle, else arange;
+            with world > 1 every rank walks the SAME global order and takes rows [rank*B, (rank+1)*B) of each global
+            batch of world*B samples (contiguous per-rank slices); a ragged last global batch is dropped
+            when drop_last, else split as evenly as the remainder allows.
+    depth:  batches in flight (pinned buffer sets).  A buffer set is reused only after the copy stream's event for its
+            last use has completed."""
+
+    def __init__(self, dataset: SpectralSmilesDataset, batch_size: int, device=None, shuffle: bool = False, seed: int = 0,
+                 rank: int = 0, world: int = 1, drop_last: bool = False, depth: int = 3):
+        self.split = TokenizedSplit(dataset)
+        self.B = int(batch_size)
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.shuffle, self.seed, self.rank, self.world, self.drop_last = shuffle, seed, rank, world, drop_last
+        self.depth = max(2, depth)
+        self.epoch = 0
+        self.max_t = int(np.diff(self.split.tgt_off).max()) if self.split.n else 1
+        self.max_n = max(1, int(np.diff(self.split.src_off).max())) if self.split.n else 1
+        self.F = None if self.split.ir is None else int(self.split.ir.shape[1])
+        self.cuda = self.device.type == "cuda"
+
+    def batches(self, epoch: int) -> List[np.ndarray]:
+        """This rank's sample indices, batch by batch, for `epoch`."""
+        n = self.split.n
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + epoch)
+            order = torch.randperm(n, generator=g).numpy()
+        else:
+            order = np.arange(n)
+        gb = self.B * self.world
+        out = []
+        for s in range(0, n, gb):
+            chunk = order[s: s + gb]
+            if len(chunk) < gb:
+                if self.drop_last or len(chunk) < self.world:
+                    break
+                per = len(chunk) // self.world                    # every rank must take part in every step
+                chunk = chunk[: per * self.world]
+                mine = chunk[self.rank * per: (self.rank + 1) * per]
+            else:
+                mine = chunk[self.rank * self.B: (self.rank + 1) * self.B]
+            out.append(mine)
+        return out
+
+    def __len__(self):
+        return len(self.batches(self.epoch))
+
+    def _host_set(self):
+        mk = (lambda *s, dtype: torch.empty(*s, dtype=dtype).pin_memory()) if self.cuda else \
+             (lambda *s, dtype: torch.empty(*s, dtype=dtype))
+        return dict(tgt=mk(self.B, self.max_t, dtype=torch.int64), nmr=mk(self.B, self.max_n, dtype=torch.int64),
+                    ir=None if self.F is None else mk(self.B, self.F, dtype=torch.float32), event=None)
+
+    def __iter__(self) -> Iterator:
+        plan = self.batches(self.epoch)
+        self.epoch += 1
+        sets = [self._host_set() for _ in range(self.depth)]
+        free: "queue.Queue[int]" = queue.Queue()
+        ready: "queue.Queue" = queue.Queue()
+        for i in range(self.depth):
+            free.put(i)
+
+        def producer():
+            try:
+                for idx in plan:
+                    k = free.get()
+                    hs = sets[k]
+                    if hs["event"] is not None:
+                        hs["event"].synchronize()                  # the copy that last read this buffer set has run
+                    tw, sw = self.split.fill(idx, hs["tgt"].numpy(), hs["nmr"].numpy(), None if hs["ir"] is None else hs["ir"].numpy())
+                    ready.put((k, len(idx), tw, sw))
+                ready.put(None)
+            except BaseException as e:                            # surfaced in the consumer
+                ready.put(e)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        while True:
+            item = ready.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            k, b, tw, sw = item
+            hs = sets[k]
+            if self.cuda:
+                with torch.cuda.stream(copy_stream):
+                    tgt = hs["tgt"][:b, :tw].to(self.device, non_blocking=True)
+                    nmr = hs["nmr"][:b, :sw].to(self.device, non_blocking=True)
+                    ir = None if hs["ir"] is None else hs["ir"][:b].to(self.device, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                hs["event"] = ev
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)                                 # the consumer's stream, not the host, waits for the copy
+                for t in (tgt, nmr, ir):
+                    if t is not None:
+                        t.record_stream(cur)
+            else:
+                tgt, nmr = hs["tgt"][:b, :tw].clone(), hs["nmr"][:b, :sw].clone()
+                ir = None if hs["ir"] is None else hs["ir"][:b].clone()
+            free.put(k)
+            yield tgt, ir, nmr, None
+        th.join()

@@ -52,8 +52,16 @@ class SmilesTokenizer:
     def convert_tokens_to_ids(self, tokens: List[str]) -> List[int]:
         return [self.vocab.get(t, self.unk_token_id) for t in tokens]
 
-    def encode(self, text: str, max_seq_length: int = 512) -> List[int]:
-        return [self.cls_token_id] + self.convert_tokens_to_ids(self.tokenize(text, max_seq_length)) + [self.sep_token_id]
+    def encode(self, text: str, max_seq_length: int = 512, add_special_tokens: bool = True, max_length=None,
+               truncation: bool = False) -> List[int]:
+        """The HuggingFace call the reference's dataset makes (train_autoregressive.py:332-337:
+        encode(s, add_special_tokens=True, max_length=L, truncation=True)): _tokenize keeps max_seq_length-2 tokens
+        (:69-72), truncation then cuts the token list so that ids + [CLS]/[SEP] fit max_length."""
+        ids = self.convert_tokens_to_ids(self.tokenize(text, max_seq_length))
+        n_special = 2 if add_special_tokens else 0
+        if truncation and max_length is not None:
+            ids = ids[: max(0, int(max_length) - n_special)]
+        return [self.cls_token_id] + ids + [self.sep_token_id] if add_special_tokens else ids
 
     def convert_tokens_to_string(self, tokens: List[str]) -> str:
         return " ".join(tokens).replace(" ##", "").strip()
