@@ -29,6 +29,7 @@ CONFIGS = {
 }
 K1_PMC = os.path.join("profiles", "r01_k1_pmc.json")
 K4_PMC = os.path.join("profiles", "r01_k4_pmc.json")
+ATTN_PMC = os.path.join("profiles", "r02_attn_pmc.json")
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide)
 
@@ -91,6 +92,28 @@ def k1_roofline(device, dtype=torch.float32, B=8192, C=64, Ln=250, iters=20):
                                "in this run)") if traffic is not None else None,
             "shape": {"B": B, "C": C, "L": Ln, "dtype": str(dtype).replace("torch.", "")},
             "algorithmic_bytes_per_launch": nbytes}
+
+
+def k1_all_shapes(device):
+    """K1 / K1b on the four encoder stage shapes (C, L) x {f32, bf16} x {fwd, bwd} at a saturating batch (traffic >= 0.4 GB
+    per launch): algorithmic bytes B*L*C*(s_in+s_out) forward, B*L*C*(2*s_in+s_out) backward, HIP events."""
+    from multimodal_amd import ops
+    out = []
+    for dtype in (torch.float32, torch.bfloat16):
+        for (B, C, Ln) in [(8192, 64, 250), (8192, 128, 125), (8192, 256, 62), (2048, 1600, 31), (2048, 2048, 31)]:
+            x = torch.rand(B, Ln, C, device=device).to(dtype)
+            w = torch.randn(C, 1, 7, device=device) * 0.3
+            b = torch.zeros(C, device=device); lw = torch.ones(C, device=device); lb = torch.zeros(C, device=device)
+            _, mean, rstd = ops.dwconv7_ln_fwd(x, w, b, lw, lb, save_stats=True)
+            dy = torch.randn_like(x)
+            tf = _event_time(lambda: ops.dwconv7_ln_fwd(x, w, b, lw, lb), iters=10)
+            tb = _event_time(lambda: ops.dwconv7_ln_bwd(x, dy, None, w, b, lw, mean, rstd), iters=10)
+            nb = B * C * Ln * x.element_size()
+            out.append({"C": C, "L": Ln, "B": B, "dtype": str(dtype).replace("torch.", ""),
+                        "fwd_us": round(tf * 1e6, 1), "fwd_GBps": round(2 * nb / tf / 1e9), "fwd_frac": round(2 * nb / tf / 1e9 / HBM_PEAK_GBPS, 3),
+                        "bwd_us": round(tb * 1e6, 1), "bwd_GBps": round(3 * nb / tb / 1e9), "bwd_frac": round(3 * nb / tb / 1e9 / HBM_PEAK_GBPS, 3)})
+            del x, dy
+    return out
 
 
 def gemm_roofline(device, M=10080, N=1600, K=6400, iters=20):
@@ -176,7 +199,14 @@ def attn_roofline(device, B=32, H=16, d=100, N=190, T=94):
     tb = _event_time(lambda: ops.prefix_attn_bwd(q, k, v, o, do, lse, H, 0, P, cos_t, sin_t, True))
     fl = 4.0 * B * S * S * E
     af, ab = fl / tf / 1e12, 2.5 * fl / tb / 1e12
-    return {"kernel": "prefix_attn_fwd2_k / prefix_attn_bwd_dq5_k + _dkv5_k", "bound": "mfma", "unit": "TFLOP/s",
+    counters = None
+    if os.path.exists(os.path.join(ROOT, ATTN_PMC)):           # rocprofv3 --pmc passes over benchmarks/attn_pmc.py, same shape
+        with open(os.path.join(ROOT, ATTN_PMC)) as fh:
+            pm = json.load(fh)
+        counters = {"source": ATTN_PMC + " (not re-measured in this run)"}
+        for kname, e in pm.items():
+            counters[kname] = {k: v for k, v in e.items() if k != "counters_per_launch" and k != "kernel_name"}
+    return {"counters": counters, "kernel": "prefix_attn_fwd2_k / prefix_attn_bwd_dq5_k + _dkv5_k", "bound": "mfma", "unit": "TFLOP/s",
             "peak": MFMA_BF16_PEAK_TFLOPS, "achieved": round(af, 1), "frac": round(af / MFMA_BF16_PEAK_TFLOPS, 4),
             "launch_us": round(tf * 1e6, 1), "bwd_achieved": round(ab, 1), "bwd_frac": round(ab / MFMA_BF16_PEAK_TFLOPS, 4),
             "bwd_launch_us": round(tb * 1e6, 1), "traffic": None,
@@ -220,15 +250,39 @@ def greedy_bench(device, world, rank):
     m = build_model(c, device).eval()
     ir, nmr, _ = synth_batch(c, B, device, 4321 + rank)
     steps = c["max_seq"]
-    with mm.compute_dtype(torch.bfloat16):
-        m.generate(nmr, ir, max_len=steps, early_stop=False)      # warm-up at the measured shape (allocator, GEMM selection)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        toks = m.generate(nmr, ir, max_len=steps, early_stop=False)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    return {"tokens_per_s_per_gpu": round(B * (toks.shape[1] - 1) / dt, 1), "batch_per_gpu": B, "steps": toks.shape[1] - 1,
-            "config": "local_config_nocat", "dtype": "bf16", "kv_cache": True, "seconds": round(dt, 4)}
+    res = {}
+    for name, dtype in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+        with mm.compute_dtype(dtype):
+            m.generate(nmr, ir, max_len=steps, early_stop=False)      # warm-up at the measured shape (allocator, GEMM selection)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            toks = m.generate(nmr, ir, max_len=steps, early_stop=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            m.generate(nmr, ir, max_len=1, early_stop=False)          # prefill + first token only
+            torch.cuda.synchronize()
+            t_pre = time.perf_counter() - t1
+        res[name] = (round(B * (toks.shape[1] - 1) / dt, 1), dt, t_pre)
+    E, H, L = c["E"], c["H"], c["L"]
+    P = 31 + c["max_nmr"]
+    n_dec = steps - 1
+    es = 2
+    # decode-loop roofline (bf16): per step every layer reads the K and V cache rows 0..pos of every sample once and the
+    # 12 E^2 weights once; achieved = those bytes over the measured time per decode step (whole loop minus the prefill)
+    kv = sum(B * 2 * (P + 1 + t) * E * es for t in range(1, steps)) * L
+    wts = 12 * E * E * es * L * n_dec
+    t_loop = max(res["bf16"][1] - res["bf16"][2], 1e-9)
+    ach = (kv + wts) / t_loop / 1e9
+    return {"tokens_per_s_per_gpu": res["bf16"][0], "batch_per_gpu": B, "steps": steps, "config": "local_config_nocat", "dtype": "bf16",
+            "kv_cache": True, "seconds": round(res["bf16"][1], 4), "prefill_seconds": round(res["bf16"][2], 4),
+            "fp32": {"tokens_per_s_per_gpu": res["f32"][0], "seconds": round(res["f32"][1], 4),
+                     "note": "the path on which token ids equal the reference's (tests/test_config_gpu.py)"},
+            "decode_loop_roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                     "frac": round(ach / HBM_PEAK_GBPS, 4), "ms_per_decode_step": round(t_loop / n_dec * 1e3, 4),
+                                     "kv_bytes_per_step_avg": kv // n_dec, "weight_bytes_per_step": wts // n_dec,
+                                     "note": "K4 (the KV read) is about half of the step at 0.61-0.64 of HBM; the rest is "
+                                             "16 short latency-bound GEMMs (M = batch rows), LayerNorm and launch gaps"}}
 
 
 def train_leg(c, device, batch, dtype, steps, warmup, rank=0):
@@ -621,6 +675,7 @@ def main():
         extras = {"roofline": roof, "roofline_bf16": roof_bf16, "roofline_mfma": gemm_roofline(device),
                   "roofline_k2": k2_roofline(device), "roofline_attn": attn_roofline(device), "roofline_decode": decode_roofline(device), "greedy": greedy}
         extras["roofline"]["config_batch_latency_us"] = k1_roofline(device, torch.float32, B=32, iters=50)["launch_us"]
+        extras["roofline_k1_all_shapes"] = k1_all_shapes(device)
         log("kernel rooflines done")
         if world == 1:
             extras["greedy_vs_recompute"] = greedy_nocache(device)

@@ -95,7 +95,10 @@ int mm_layernorm_bwd_sums(const void* x, const void* dy, const void* dres, const
  *   if gamma: acc *= gamma[n]            (LayerScale, convnext.py:45)
  *   if rowscale: acc *= rowscale[m / rows_per_scale]   (DropPath factor, convnext.py:17)
  *   if res:  acc += res[m][n]            (residual, convnext.py:47)
- * split_k > 1 needs workspace of split_k*M*N floats and a plain epilogue (bias only). */
+ * split_k > 1 needs workspace of split_k*M*N floats and a plain epilogue (bias only).
+ * split_k <= 1 with a workspace given (any size; 8*M*N floats covers every case): the library may split K on its own for
+ * skinny problems with a deep K (about 1000 rows: encoder stage 3 at the config batch, decode steps), keeping the full
+ * epilogue (it is applied by the reduction pass); without a workspace it never splits. */
 typedef struct {
     const void* A; const void* B; void* out;
     int64_t M, N, K;

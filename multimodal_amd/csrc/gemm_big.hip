@@ -17,6 +17,7 @@
 #include "gemm_epi.h"
 #include <stdlib.h>
 #include <utility>
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -61,6 +62,32 @@ template <typename TO, int TM, int TN, int EPI_ROW>
 __device__ __forceinline__ void big_epilogue(const GemmP& p, f32x4_t (&acc)[TM][TN], unsigned char* wl, long mw, long nw, int lane) {
     const int fr = lane & 15, fg = lane >> 4;
     constexpr int LPR = TN * 2;                        // lanes per row (8 columns each)
+    if (p.partial) {                                    // split-K: raw accumulators into this split's slab [M][N] (f32)
+        float* slab = p.partial + (long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int pass = 0; pass < TM; pass++) {
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                *reinterpret_cast<f32x4_t*>(wl + fr * EPI_ROW + ((j * 4 + fg) << 4)) = acc[pass][j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+            for (int idx = lane; idx < 16 * TN * 4; idx += 64) {
+                const int row = idx / (TN * 4), c4 = idx % (TN * 4);
+                const long m = mw + pass * 16 + row, n = nw + c4 * 4;
+                if (m < p.M && n < p.N) {
+                    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(wl + row * EPI_ROW + c4 * 16);
+                    if (n + 4 <= p.N && (p.N & 3) == 0) *reinterpret_cast<f32x4_t*>(slab + m * p.N + n) = v;
+                    else for (int e = 0; e < 4 && n + e < p.N; e++) slab[m * p.N + n + e] = v[e];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        return;
+    }
     const bool fast = p.o_vec && (p.N & 7) == 0 && !(p.mul && p.res) && !p.gamma && !p.rowscale;   // block-uniform
     auto wave_sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -158,7 +185,9 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_k(const GemmP p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WN, wc = wave % WN;
-    const int nk = p.K / BK;
+    // split-K (skinny problems with a deep K): blockIdx.y owns K steps [kt0, kt0 + nk) and leaves a raw f32 slab
+    const int kt0 = p.partial ? blockIdx.y * (p.k_per_split / BK) : 0;
+    const int nk = p.partial ? min(p.K / BK - kt0, p.k_per_split / BK) : p.K / BK;
     const int nwg = p.tiles_m * p.tiles_n;
 
     // ---- fragment read offsets (bytes inside a stage)
@@ -198,7 +227,7 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_k(const GemmP p) {
         for (int i = 0; i < G::PPW; i++) {
             const int q = wave + G::NW * i;
             if (q < G::PIECES)                                         // wave-uniform
-                __builtin_amdgcn_global_load_lds((glb_vp)(src[i] + (long)kt * BK), (lds_vp)(base + q * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_vp)(src[i] + (long)(kt0 + kt) * BK), (lds_vp)(base + q * 1024), 16, 0, 0);
         }
     };
 
@@ -241,8 +270,29 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_k(const GemmP p) {
     }
 }
 
+// split-K second stage with the FULL fused epilogue: sum the slabs in a fixed order, then bias / act / mul / gamma / rowscale /
+// residual exactly as the one-pass kernels do (4 consecutive columns per thread)
+template <typename TO>
+__global__ __launch_bounds__(256) void big_splitk_epilogue_k(GemmP p, int splits) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const long nq = (p.N + 3) / 4;
+    if (q >= (long)p.M * nq) return;
+    const long m = q / nq, n = (q % nq) * 4;
+    const float* src = p.partial + m * p.N + n;
+    const long slab = (long)p.M * p.N;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = (p.N & 3) == 0;
+    for (int z = 0; z < splits; z++) {
+        if (vec) { const f32x4_t t = *reinterpret_cast<const f32x4_t*>(src + z * slab); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+        else for (int e = 0; e < 4 && n + e < p.N; e++) v[e] += src[z * slab + e];
+    }
+    const float rscale = p.rowscale ? p.rowscale[m / p.rows_per_scale] : 1.f;
+    p.partial = nullptr;
+    gemm_epilogue4<TO, false>(p, v, m, n, rscale, 0);
+}
+
 template <typename TO, int TM, int TN, int WN>
-int launch_big(const GemmP& p, hipStream_t st) {
+int launch_big(const GemmP& p, hipStream_t st, int splits = 1) {
     typedef BigTile<TM, TN, WN> G;
     static bool attr_set = false;
     if (!attr_set) {
@@ -251,20 +301,44 @@ int launch_big(const GemmP& p, hipStream_t st) {
         attr_set = true;
     }
     const int tiles = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((gemm_big_k<TO, TM, TN, WN>), dim3((unsigned)tiles), dim3(128 * WN), G::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_big_k<TO, TM, TN, WN>), dim3((unsigned)tiles, (unsigned)splits), dim3(128 * WN), G::LDS_BYTES, st, p);
     MM_LAUNCH_CHECK();
+    if (p.partial) {
+        const long nq = (long)p.M * ((p.N + 3) / 4);
+        hipLaunchKernelGGL(big_splitk_epilogue_k<TO>, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, st, p, splits);
+        MM_LAUNCH_CHECK();
+    }
     return MM_OK;
 }
 
-struct Shape { int tm, tn; };
-constexpr Shape kShapes[] = {{8, 4}, {7, 4}, {8, 5}, {7, 5}};
+struct Shape { int tm, tn, wn; };
+// 8-wave shapes (256x256 class) for problems that fill the chip with them, 4-wave shapes (128x128, 64x128; two or three
+// workgroups per CU) for skinny problems -- M of about 1000 rows: the encoder's stage-3 products at the config batch and the
+// decode-step products -- where the big tiles would leave most CUs idle.
+constexpr Shape kShapes[] = {{8, 4, 4}, {7, 4, 4}, {8, 5, 4}, {7, 5, 4}, {4, 4, 2}, {2, 4, 2}};
+constexpr int kNumShapes = 6;
 
-// Estimated time of a tile shape: rounds of (at most one tile per CU) x (K steps x MFMA work + fixed prologue/epilogue).
-double shape_cost(const GemmP& p, Shape s) {
-    const long tiles = cdiv(p.M, 32 * s.tm) * cdiv(p.N, 64 * s.tn);
-    const long rounds = cdiv(tiles, kNumCU);
-    const double iter = 1.62 * (s.tm * s.tn) / 32.0;       // us per K step, measured on the 256x256 shape
-    return rounds * ((p.K / BK) * iter + 12.0);
+// Estimated time of a tile shape: rounds of (workgroups resident per CU) x (K steps x MFMA work + fixed prologue/epilogue).
+double shape_cost(const GemmP& p, Shape s, bool allow_split = false) {
+    const long tiles = cdiv(p.M, 32 * s.tm) * cdiv(p.N, 16 * s.tn * s.wn);
+    const int per_cu = s.wn == 4 ? 1 : (s.tm == 4 ? 2 : 3);            // by LDS: 2 x (BM + BN) x 128 bytes per workgroup
+    const long rounds = cdiv(tiles, (long)kNumCU * per_cu);
+    // us per K step: 1.62 measured on the 256x256 shape (8 waves = two per SIMD sharing a matrix pipe).  A 4-wave workgroup
+    // puts one wave on each SIMD; c co-resident workgroups give c waves per SIMD.  A step cannot beat its load latency.
+    const long conc = s.wn == 4 ? 2 : std::min<long>(per_cu, cdiv(tiles, kNumCU));
+    // measured alone on a CU: 0.65 us per step for the 128x128 shape, 0.52 for 64x128 (load latency, not MFMA work)
+    const double floor_us = s.wn == 4 ? 0.40 : 0.38 + 0.017 * s.tm * s.tn;
+    const double iter = std::max(floor_us, 1.62 * (s.tm * s.tn) / 32.0 * conc / 2.0);
+    const double fixed = s.wn == 4 ? 12.0 : 7.0;
+    if (s.wn != 4 && allow_split) {                          // split-K fills the chip: K steps divide, a reduce pass is added
+        const long sp = std::max<long>(1, std::min<long>({8, (long)kNumCU * per_cu / std::max<long>(tiles, 1), (long)(p.K / BK) / 8}));
+        if (sp > 1) {
+            const long c2 = std::min<long>(per_cu, cdiv(tiles * sp, kNumCU));
+            const double it2 = std::max(floor_us, 1.62 * (s.tm * s.tn) / 32.0 * c2 / 2.0);
+            return cdiv(tiles * sp, (long)kNumCU * per_cu) * (cdiv(p.K / BK, sp) * it2 + fixed) + 4.0 + (double)sp * p.M * p.N * 8.0 / 4e6;
+        }
+    }
+    return rounds * ((p.K / BK) * iter + fixed);
 }
 }  // namespace
 
@@ -272,27 +346,56 @@ double shape_cost(const GemmP& p, Shape s) {
 bool gemm_big_applicable(const GemmP& p, int dtype, int a_kmajor, int b_kmajor, int splits) {
     if (dtype != MM_BF16 || a_kmajor || b_kmajor || splits > 1 || p.partial) return false;
     if (!p.a_vec || !p.b_vec || p.K % BK != 0) return false;
-    return (long)p.M * p.N >= 256L * 256 * 64;            // at least a quarter of the chip in 256x256 tiles
+    // 256x256-class tiles from a quarter of the chip up; the 4-wave shapes for skinny problems from about 1000 x 1000 x 1000
+    // (measured: below that gemm_k's 64x64 tiles are as fast -- 13 us at 1984 x 1024 x 256 either way -- and the
+    // one-K-step products of the first encoder stages are slower here)
+    static const long min_mn = getenv("MM_GEMM_BIG_MIN_MN") ? atol(getenv("MM_GEMM_BIG_MIN_MN")) : 256L * 256 * 12;
+    if ((long)p.M * p.N >= 256L * 256 * 64) return true;
+    return (long)p.M * p.N >= min_mn && p.M >= 64 && p.N >= 1024 && p.K >= 1024;
 }
 
-int gemm_big_launch(GemmP& p, int out_dtype, hipStream_t st) {
+// Split-K for a 4-wave shape: when its tiles leave most of the chip idle and K is deep, cut K so that about
+// kNumCU * per_cu workgroups exist; each split must keep >= 8 K steps.  Needs splits * M * N floats of caller workspace.
+static int pick_splits(const GemmP& p, Shape s, size_t ws_bytes) {
+    if (s.wn == 4) return 1;
+    const long tiles = cdiv(p.M, 32 * s.tm) * cdiv(p.N, 16 * s.tn * s.wn);
+    const int per_cu = s.tm == 4 ? 2 : 3;
+    long sp = std::min<long>({8, (long)kNumCU * per_cu / std::max<long>(tiles, 1), (long)(p.K / BK) / 8});
+    while (sp > 1 && (size_t)sp * p.M * p.N * sizeof(float) > ws_bytes) sp--;
+    return (int)std::max<long>(sp, 1);
+}
+
+int gemm_big_launch(GemmP& p, int out_dtype, hipStream_t st, void* ws, size_t ws_bytes) {
     // 8-wide access to the out family: 16-byte aligned bases, row stride a multiple of 16 bytes
     const int osz = out_dtype == MM_BF16 ? 2 : 4;
     auto al = [&](const void* q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
     p.o_vec = (p.ldo * osz) % 16 == 0 && al(p.out) && al(p.pre) && al(p.mul) && al(p.res);
     int best = 0;
-    static const char* force = getenv("MM_GEMM_BIG_SHAPE");              // "0".."3": benchmark override
-    if (force) best = atoi(force) & 3;
+    static const char* force = getenv("MM_GEMM_BIG_SHAPE");              // "0".."5": benchmark override
+    if (force) best = atoi(force) % kNumShapes;
     else
-        for (int i = 1; i < 4; i++) if (shape_cost(p, kShapes[i]) < shape_cost(p, kShapes[best]) * 0.97) best = i;
+        for (int i = 1; i < kNumShapes; i++)
+            if (shape_cost(p, kShapes[i], ws != nullptr) < shape_cost(p, kShapes[best], ws != nullptr) * 0.97) best = i;
     const Shape s = kShapes[best];
-    p.tiles_m = (int)cdiv(p.M, 32 * s.tm); p.tiles_n = (int)cdiv(p.N, 64 * s.tn);
-#define GO_(TM_, TN_) return out_dtype == MM_BF16 ? launch_big<bf16, TM_, TN_, 4>(p, st) : launch_big<float, TM_, TN_, 4>(p, st)
+    p.tiles_m = (int)cdiv(p.M, 32 * s.tm); p.tiles_n = (int)cdiv(p.N, 16 * s.tn * s.wn);
+    static const char* fsp = getenv("MM_GEMM_BIG_SPLITS");               // benchmark override
+    int splits = ws ? (fsp ? atoi(fsp) : pick_splits(p, s, ws_bytes)) : 1;
+    if (s.wn == 4 || (size_t)splits * p.M * p.N * sizeof(float) > ws_bytes) splits = 1;
+    if (splits > 1) {
+        const int steps = (int)cdiv(p.K / BK, splits);
+        p.k_per_split = steps * BK;
+        splits = (int)cdiv(p.K / BK, steps);
+        p.partial = splits > 1 ? (float*)ws : nullptr;
+    }
+    if (splits <= 1) { splits = 1; p.partial = nullptr; p.k_per_split = p.K; }
+#define GO_(TM_, TN_, WN_) return out_dtype == MM_BF16 ? launch_big<bf16, TM_, TN_, WN_>(p, st, splits) : launch_big<float, TM_, TN_, WN_>(p, st, splits)
     switch (best) {
-        case 0: GO_(8, 4);
-        case 1: GO_(7, 4);
-        case 2: GO_(8, 5);
-        default: GO_(7, 5);
+        case 0: GO_(8, 4, 4);
+        case 1: GO_(7, 4, 4);
+        case 2: GO_(8, 5, 4);
+        case 3: GO_(7, 5, 4);
+        case 4: GO_(4, 4, 2);
+        default: GO_(2, 4, 2);
     }
 #undef GO_
 }

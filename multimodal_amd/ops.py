@@ -225,6 +225,11 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool = False
         nbytes = split_k * M * N * 4
         ws = workspace(nbytes, A.device, ws_tag)       # a caller on a second stream passes its own tag
         a.workspace, a.workspace_bytes = L.ptr(ws), nbytes
+    elif M * N <= (1 << 22) and K >= 2048 and not a_kmajor and not b_kmajor and A.dtype == torch.bfloat16:
+        # skinny and deep: let the library split K on its own (full epilogue kept); 8 slabs cover every choice it makes
+        nbytes = 8 * M * N * 4
+        ws = workspace(nbytes, A.device, ws_tag + "_auto")
+        a.workspace, a.workspace_bytes = L.ptr(ws), nbytes
     L.check(L.lib().mm_gemm(C.byref(a), L.cur_stream()), "mm_gemm")
     return out
 

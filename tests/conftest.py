@@ -71,8 +71,15 @@ def config_meta():
         return json.load(fh)
 
 
-def check_grads_against_golden(grads, g, tol, name=""):
-    """grads: {parameter name: gradient tensor}; g: a golden npz dict with 'grad.<name>' entries (nmr_embed by rows)."""
+def l2_err(a, b):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def check_grads_against_golden(grads, g, tol, name="", l2_tol=None):
+    """grads: {parameter name: gradient tensor}; g: a golden npz dict with 'grad.<name>' entries (nmr_embed by rows).
+    tol bounds the max-norm error of every tensor, l2_tol (optional) its relative L2 error."""
     n = 0
     for k, v in g.items():
         if not k.startswith("grad.") or k == "grad.ir" or k.endswith(".rows"):
@@ -81,5 +88,7 @@ def check_grads_against_golden(grads, g, tol, name=""):
         if k + ".rows" in g:
             got = got[torch.from_numpy(g[k + ".rows"])]
         assert rel_err(got, v) < tol, (name, k, rel_err(got, v))
+        if l2_tol is not None:
+            assert l2_err(got, v) < l2_tol, (name, k, l2_err(got, v))
         n += 1
     return n
