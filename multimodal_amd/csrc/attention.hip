@@ -14,15 +14,7 @@
 #include <type_traits>
 #include <stdlib.h>
 
-struct AttnP {
-    const void* q; const void* k; const void* v; void* o; float* lse;
-    const void* dO; void* dq; void* dk; void* dv; const float* delta;
-    const float* cos_t; const float* sin_t;
-    int B, H, S, d, rot, P;
-    long ld, ld_o, ld_d;
-    float scale;
-    int vec_ok;
-};
+#include "attention.h"
 
 template <typename T> struct AT;
 template <> struct AT<bf16> { static constexpr int KT = 32, PAD = 8, KSTEP = 32; };
@@ -267,6 +259,10 @@ __global__ __launch_bounds__(256) void prefix_attn_fwd_k(const AttnP p) {
 // the next tile's global loads are issued BEFORE the current tile is multiplied (register prefetch), so a
 // tile costs one barrier pair and no exposed load latency.
 // ------------------------------------------------------------------------------------------------
+// LDS row padding of the fast kernels: a row stride of DP/2 + 8 dwords is an odd multiple of 8 banks, so the 8 rows x 32 bytes
+// of a ds_read_b64_tr_b16 half-wave cover all 64 banks once (with + 8 elements the rows overlapped pairwise: 40 % conflict
+// cycles measured), and the ds_read_b128 fragment reads stay conflict-free
+constexpr int FPAD = 16;
 template <int DP, int NROWS>
 struct TileRegs { static constexpr int IT = NROWS * (DP / 4) / 256; uint2 v[IT]; };
 
@@ -327,7 +323,7 @@ __device__ __forceinline__ bf16x8_t frag_load(const bf16* __restrict__ g, long l
 template <int DP, int KT, bool STABLE>
 __global__ __launch_bounds__(256, (DP <= 128 ? FWD_WAVES : 1)) void prefix_attn_fwd2_k(const AttnP p) {
     typedef bf16 T;
-    constexpr int PITCH = DP + 8;
+    constexpr int PITCH = DP + FPAD;
     constexpr int NKS = DP / 32, NDV = DP / 16, NT16 = KT / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* lk = reinterpret_cast<T*>(smem);
@@ -450,7 +446,7 @@ __global__ __launch_bounds__(256, (DP <= 128 ? FWD_WAVES : 1)) void prefix_attn_
 
 template <int DP, int KT>
 static int fwd2_launch(const AttnP& p, int mode, hipStream_t st) {
-    const size_t lds = (size_t)2 * KT * (DP + 8) * 2;
+    const size_t lds = (size_t)2 * KT * (DP + FPAD) * 2;
     const dim3 grid((unsigned)cdiv(p.S, 64), (unsigned)(p.B * p.H));
     if (mode == MM_ATTN_STABLEMAX) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)prefix_attn_fwd2_k<DP, KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -539,7 +535,11 @@ extern "C" int mm_prefix_attn_fwd(const void* q, const void* k, const void* v, v
     p.vec_ok = attn_vec_ok(q, k, v, ld_qkv, d, dtype);
     hipStream_t st = (hipStream_t)stream;
     static const bool force_generic = getenv("MM_ATTN_GENERIC") != nullptr;     // A/B switch for debugging
-    if (!force_generic && dtype == MM_BF16 && rot == 0 && p.vec_ok && ((uintptr_t)o) % 8 == 0) return fwd2_dispatch(p, mode, st);
+    static const bool force_v2 = getenv("MM_ATTN_V2") != nullptr;               // A/B switch: the previous fast generation
+    if (!force_generic && dtype == MM_BF16 && rot == 0 && p.vec_ok && ((uintptr_t)o) % 8 == 0) {
+        if (!force_v2 && attn_fast_ok(p)) return attn_fast_fwd(p, mode, st);
+        return fwd2_dispatch(p, mode, st);
+    }
     return dtype == MM_BF16 ? fwd_dispatch<bf16>(p, mode, st) : fwd_dispatch<float>(p, mode, st);
 }
 
@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(256) void prefix_attn_bwd_dkv4_k(const AttnP p) {
 template <int DP, int KT, bool STABLE>
 __global__ __launch_bounds__(256, (DP <= 128 ? DQ_WAVES : 1)) void prefix_attn_bwd_dq5_k(const AttnP p) {
     typedef bf16 T;
-    constexpr int PITCH = DP + 8;
+    constexpr int PITCH = DP + FPAD;
     constexpr int NKS = DP / 32, NDV = DP / 16, NT16 = KT / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* lk = reinterpret_cast<T*>(smem);
@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(256, (DP <= 128 ? DQ_WAVES : 1)) void prefix_attn_b
 template <int DP, int QT, bool STABLE>
 __global__ __launch_bounds__(256, (DP <= 128 ? DKV_WAVES : 1)) void prefix_attn_bwd_dkv5_k(const AttnP p) {
     typedef bf16 T;
-    constexpr int PITCH = DP + 8;
+    constexpr int PITCH = DP + FPAD;
     constexpr int NKS = DP / 32, NDV = DP / 16, NT16 = QT / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* lq = reinterpret_cast<T*>(smem);
@@ -1382,7 +1382,7 @@ __global__ __launch_bounds__(256, (DP <= 128 ? DKV_WAVES : 1)) void prefix_attn_
 
 template <int DP, int KT, int QT = KT>
 static int bwd_launch5(const AttnP& p, int mode, hipStream_t st) {
-    constexpr int PITCH = DP + 8;
+    constexpr int PITCH = DP + FPAD;
     constexpr int RT = KT > QT ? KT : QT;
     const size_t lds = (size_t)2 * RT * PITCH * 2 + 2 * RT * sizeof(float);
     const dim3 grid((unsigned)cdiv(p.S, 64), (unsigned)(p.B * p.H));
@@ -1513,7 +1513,11 @@ extern "C" int mm_prefix_attn_bwd(const void* q, const void* k, const void* v, c
     static const bool force_generic = getenv("MM_ATTN_GENERIC") != nullptr;     // A/B switch for debugging
     const bool al8 = (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8) == 0 && ld_dqkv % 4 == 0;
     // measured: the fast form wins up to d = 192 (1.05-1.5x); beyond that its register footprint loses to the staged kernels
-    if (!force_generic && dtype == MM_BF16 && rot == 0 && p.vec_ok && al8 && d <= 192) return bwd_dispatch5(p, mode, st);
+    static const bool force_v2 = getenv("MM_ATTN_V2") != nullptr;               // A/B switch: the previous fast generation
+    if (!force_generic && dtype == MM_BF16 && rot == 0 && p.vec_ok && al8 && d <= 192) {
+        if (!force_v2 && attn_fast_ok(p)) return attn_fast_bwd(p, mode, st);
+        return bwd_dispatch5(p, mode, st);
+    }
     return dtype == MM_BF16 ? bwd_dispatch4(p, mode, st) : bwd_dispatch<float>(p, mode, st);
 }
 
