@@ -1721,6 +1721,24 @@ __global__ void kv_cache_fill_k(const T* __restrict__ k, const T* __restrict__ v
     vc[dst] = v[src + c];
 }
 
+// rot == 0 (keys already rotated by mm_rope_inplace), d % 8 == 0, 16-byte aligned rows: a pure layout change
+// [B][S][H][d] -> [B][H][Smax][d], 16 bytes per lane both ways (the element-wise kernel above moved 0.8 TB/s)
+__global__ __launch_bounds__(256) void kv_cache_fill_v_k(const bf16* __restrict__ k, const bf16* __restrict__ v, bf16* __restrict__ kc,
+                                                          bf16* __restrict__ vc, int H, int S, int d8, int Smax, long ld, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // over [B][S][H][d/8]
+    if (idx >= total) return;
+    const int c = (int)(idx % d8);
+    const long t = idx / d8;
+    const int h = (int)(t % H);
+    const long bs = t / H;
+    const int s = (int)(bs % S);
+    const long b = bs / S;
+    const long src = bs * ld + (long)h * d8 * 8 + c * 8;
+    const long dst = ((b * H + h) * Smax + s) * (long)d8 * 8 + c * 8;
+    *reinterpret_cast<mm_u4_t*>(kc + dst) = *reinterpret_cast<const mm_u4_t*>(k + src);
+    *reinterpret_cast<mm_u4_t*>(vc + dst) = *reinterpret_cast<const mm_u4_t*>(v + src);
+}
+
 extern "C" int mm_kv_cache_fill(const void* k, const void* v, void* kcache, void* vcache, const float* cos_t,
                                 const float* sin_t, int64_t B, int64_t H, int64_t S, int64_t d, int64_t rot, int64_t Smax,
                                 int64_t ld_qkv, int dtype, void* stream) {
@@ -1728,9 +1746,17 @@ extern "C" int mm_kv_cache_fill(const void* k, const void* v, void* kcache, void
     MM_CHECK(B > 0 && H > 0 && S > 0 && d > 0 && S <= Smax, "kv_cache_fill: bad shape (S=%lld Smax=%lld)", (long long)S, (long long)Smax);
     MM_CHECK(rot >= 0 && rot <= d && rot % 2 == 0 && (rot == 0 || (cos_t && sin_t)), "kv_cache_fill: bad rot/tables");
     MM_CHECK(ld_qkv >= H * d, "kv_cache_fill: ld too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MM_BF16 && rot == 0 && d % 8 == 0 && ld_qkv % 8 == 0 &&
+        (((uintptr_t)k | (uintptr_t)v | (uintptr_t)kcache | (uintptr_t)vcache) % 16) == 0) {
+        const long tot8 = B * S * H * (d / 8);
+        hipLaunchKernelGGL(kv_cache_fill_v_k, dim3((unsigned)cdiv(tot8, 256)), dim3(256), 0, st, (const bf16*)k, (const bf16*)v,
+                           (bf16*)kcache, (bf16*)vcache, (int)H, (int)S, (int)(d / 8), (int)Smax, (long)ld_qkv, tot8);
+        MM_LAUNCH_CHECK();
+        return MM_OK;
+    }
     const long total = B * S * H * d;
     const dim3 grid((unsigned)cdiv(total, 256));
-    hipStream_t st = (hipStream_t)stream;
     if (dtype == MM_BF16) hipLaunchKernelGGL(kv_cache_fill_k<bf16>, grid, dim3(256), 0, st, (const bf16*)k, (const bf16*)v, (bf16*)kcache, (bf16*)vcache, cos_t, sin_t, (int)B, (int)H, (int)S, (int)d, (int)rot, (int)Smax, (long)ld_qkv);
     else if (dtype == MM_F32) hipLaunchKernelGGL(kv_cache_fill_k<float>, grid, dim3(256), 0, st, (const float*)k, (const float*)v, (float*)kcache, (float*)vcache, cos_t, sin_t, (int)B, (int)H, (int)S, (int)d, (int)rot, (int)Smax, (long)ld_qkv);
     else MM_FAIL(MM_ERR_ARG, "kv_cache_fill: bad dtype %d", dtype);

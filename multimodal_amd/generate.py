@@ -7,11 +7,13 @@ LayerNorm -> fused QKV projection (M = batch rows) -> K4 (rotate, append to cach
 MLP.  Batch-sharded across GPUs with no collective: each rank owns its rows and its cache."""
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import Dict, List, Optional
 
 import torch
 
+from . import _lib as L
 from . import functional as FN
 from . import ops
 
@@ -46,6 +48,7 @@ def _lin(x2, w, b, b16=None, act=0, res=None, out_dtype=None, square=False):
     for the square E x E product (13.0 vs 15.0 us), the library wins for N = 3E / 4E and K = 4E (13.5-21.5 vs 22-45 us),
     so those run there with the bias in the library's epilogue and relu^2 / the residual as one libmmhip / in-place pass.
     b is the float32 bias (libmmhip epilogue), b16 its compute-dtype copy from the operand cache (library epilogue)."""
+    # `square`: this product runs on libmmhip in bf16 (the E x E products, and d_model -> d_ffn with its relu^2)
     use_mm = _DECODE_GEMM == "mm" or (_DECODE_GEMM == "auto" and square and x2.dtype == torch.bfloat16)
     if use_mm:
         return ops.gemm(x2, w, x2.shape[0], w.shape[0], w.shape[1], bias=b, act=act, res=res, out_dtype=out_dtype)
@@ -55,6 +58,111 @@ def _lin(x2, w, b, b16=None, act=0, res=None, out_dtype=None, square=False):
     if res is not None:
         y.add_(res)
     return y if out_dtype in (None, y.dtype) else y.to(out_dtype)
+
+
+class _StepPlan:
+    """One decode step for a fixed batch as a flat list of PREPARED launches.  The step is about 40 short kernels (13-25 us
+    products at M = batch rows, 140 us of K4 per layer); issued through the checking wrappers of ops.py (allocation, shape
+    checks, pointer conversion: about 30 us of Python per call) the loop was host-bound at 1.37 ms per step for 1.0 ms of
+    kernels.  Here every buffer is allocated once, every C-ABI argument list is built once (only the K4 position changes),
+    the library products write into preallocated outputs, and the token ids live in a [steps+1, B] table whose row t+1 is
+    the argmax kernel's output AND the next step's input: no per-step copies, casts or bookkeeping kernels.
+    Per product (measured, bf16, M = 1024, benchmarks/decode_bench.py gemm): fused q/k/v on the library (13.4 vs 17.4 us), the
+    square out-projection with bias + residual on libmmhip (13.1 vs 15.3), d_model -> d_ffn with bias + relu^2 on libmmhip
+    (18.8 vs 15.2 + 5), d_ffn -> d_model on the library + one in-place add (21.4 vs 25.4).  float32: library products."""
+
+    def __init__(self, dec, weights, cache, w_out, b_out, b_out16, emb_dt, ids, B, dt, dev, Smax):
+        lib = L.lib()
+        self.stream = L.cur_stream()
+        st = self.stream
+        E, H = dec.embed_dim, dec.num_heads
+        d = E // H
+        bf = dt == torch.bfloat16
+        code = L.MM_BF16 if bf else L.MM_F32
+        new = lambda *shape, dtype=dt: torch.empty(shape, dtype=dtype, device=dev)
+        x0, x1, xa, qkv, att, xf = new(B, E), new(B, E), new(B, E), new(B, 3 * E), new(B, E), new(B, E)
+        F4 = dec.layers[0].ffn_w1.weight.shape[0]
+        u = new(B, F4)
+        V = w_out.shape[0]
+        logits = new(B, V)
+        self.keep = [x0, x1, xa, qkv, att, xf, u, logits, weights, w_out, b_out, b_out16, emb_dt, ids, cache]
+        self.x0, self.emb, self.ids = x0, emb_dt, ids
+        calls = []                              # (callable, args) ; args None -> plain Python callable
+        self.k4 = []                            # indices of the K4 entries (their position argument changes per step)
+
+        def c(name, *args):
+            calls.append((getattr(lib, name), name, list(args)))
+
+        def gemm(a, w, out, bias=None, act=0, res=None):
+            g = L.GemmArgs()
+            g.A, g.B, g.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
+            g.M, g.N, g.K = a.shape[0], w.shape[0], w.shape[1]
+            g.lda, g.ldb, g.ldo = a.stride(0), w.stride(0), out.stride(0)
+            g.dtype, g.out_dtype = code, code
+            g.bias = bias.data_ptr() if bias is not None else None
+            g.act = act
+            g.res = res.data_ptr() if res is not None else None
+            g.split_k = 1
+            if bf and g.M * g.N <= (1 << 22) and g.K >= 2048:      # skinny and deep: room for the library's own K split
+                ws = ops.workspace(8 * g.M * g.N * 4, dev, "gemm_auto")
+                g.workspace, g.workspace_bytes = ws.data_ptr(), 8 * g.M * g.N * 4
+            self.keep.append(g)
+            calls.append((lib.mm_gemm, "mm_gemm", [C.byref(g), st]))
+
+        def addmm(bias, a, w, out):
+            wt = w.t()
+            calls.append((lambda: torch.addmm(bias, a, wt, out=out), None, None))
+
+        def ln(x, norm, y):
+            c("mm_layernorm_fwd", x.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), y.data_ptr(), None, None, 1, B, B, E,
+              float(norm.eps), code, st)
+
+        for li, layer in enumerate(dec.layers):
+            w = weights[li]
+            cos_t, sin_t = layer.rotary_emb.half_tables(Smax)
+            self.keep += [cos_t, sin_t]
+            ln(x0, layer.attn_norm, xa)
+            addmm(w["bqkv16"], xa, w["wqkv"], qkv)
+            self.k4.append(len(calls))
+            c("mm_decode_attn", qkv.data_ptr(), qkv.data_ptr() + E * qkv.element_size(), qkv.data_ptr() + 2 * E * qkv.element_size(),
+              cache.k[li].data_ptr(), cache.v[li].data_ptr(), att.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), B, H, d,
+              layer.rotary_ndims, 0, Smax, 3 * E, int(layer.use_stablemax), code, st)
+            if bf:
+                gemm(att, w["wo"], x1, bias=w["bo"], res=x0)
+            else:
+                addmm(w["bo"], att, w["wo"], x1)
+                calls.append((lambda: x1.add_(x0), None, None))
+            ln(x1, layer.mlp_norm, xf)
+            if bf:
+                gemm(xf, w["w1"], u, bias=w["b1"], act=ops.ACT_RELU2)
+            else:
+                addmm(w["b116"], xf, w["w1"], u)
+                c("mm_relu2_fwd", u.data_ptr(), u.data_ptr(), u.numel(), code, st)
+            addmm(w["b216"], u, w["w2"], x0)
+            calls.append((lambda: x0.add_(x1), None, None))
+        ln(x0, dec.final_norm, xa)
+        addmm(b_out16, xa, w_out, logits)
+        self.argmax = len(calls)
+        c("mm_argmax_rows", logits.data_ptr(), 0, B, V, logits.stride(0), code, st)
+        self.calls = calls
+        self.POS = 12                           # index of `pos` in mm_decode_attn's argument list
+        self.id_bytes = ids.stride(0) * ids.element_size()
+        self.ids_ptr = ids.data_ptr()
+
+    def step(self, t: int, pos: int) -> None:
+        """ids[t] (at sequence position pos - 1) -> ids[t + 1]."""
+        torch.index_select(self.emb, 0, self.ids[t], out=self.x0)
+        calls = self.calls
+        for i in self.k4:
+            calls[i][2][self.POS] = pos
+        calls[self.argmax][2][1] = self.ids_ptr + (t + 1) * self.id_bytes
+        for fn, name, args in calls:
+            if args is None:
+                fn()
+            else:
+                rc = fn(*args)
+                if rc or L._TRACE:
+                    L.check(rc, name)
 
 
 @torch.no_grad()
@@ -100,9 +208,12 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
         # the big prefill products stay on the library where it wins (N = 3E, 4E: DESIGN.md 4), the N = E products with
         # their bias + residual run on the large-tile kernel, as in the training forward
         qkv = torch.addmm(w["bqkv16"], xa.view(M0, E), w["wqkv"].t()).view(B, S0, 3, E)
-        ops.kv_cache_fill(qkv[:, :, 1], qkv[:, :, 2], cache.k[li], cache.v[li], H, layer.rotary_ndims, cos_t, sin_t)
-        a, _ = ops.prefix_attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], H, layer.rotary_ndims, P, cos_t, sin_t,
-                                   layer.use_stablemax)
+        rot = layer.rotary_ndims
+        if dt == torch.bfloat16 and rot > 0:       # rotate q,k once in place: cache fill becomes a copy, K3 runs its fast form
+            ops.rope_inplace(qkv.view(B, S0, 3 * E)[:, :, :2 * E], 2 * H, rot, cos_t, sin_t)
+            rot = 0
+        ops.kv_cache_fill(qkv[:, :, 1], qkv[:, :, 2], cache.k[li], cache.v[li], H, rot, cos_t, sin_t)
+        a, _ = ops.prefix_attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], H, rot, P, cos_t, sin_t, layer.use_stablemax)
         x = _lin(a.view(M0, E), w["wo"], w["bo"], res=x.view(M0, E), square=True).view(B, S0, E)
         xf, _, _ = ops.layernorm_fwd(x, layer.mlp_norm.weight, layer.mlp_norm.bias)
         u = ops.relu2_fwd(torch.addmm(w["b116"], xf.view(M0, E), w["w1"].t()))
@@ -127,7 +238,7 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
                                 layer.rotary_ndims, pos, cos_t, sin_t, layer.use_stablemax)
             h = _lin(a, w["wo"], w["bo"], res=h, square=True)
             xf, _, _ = ops.layernorm_fwd(h, layer.mlp_norm.weight, layer.mlp_norm.bias)
-            u = _lin(xf, w["w1"], w["b1"], w["b116"], act=ops.ACT_RELU2)
+            u = _lin(xf, w["w1"], w["b1"], w["b116"], act=ops.ACT_RELU2, square=True)      # libmmhip: bias + relu^2 fused
             h = _lin(u, w["w2"], w["b2"], w["b216"], res=h)
         xt, _, _ = ops.layernorm_fwd(h, dec.final_norm.weight, dec.final_norm.bias)
         return ops.argmax_rows(_lin(xt, w_out, b_out, b_out16, out_dtype=torch.float32))
@@ -166,13 +277,17 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
             g.replay()
             n_done = t + 1
     else:
+        ids = torch.empty((steps + 1, B), dtype=torch.long, device=dev)          # row t+1: argmax output and next input
+        ids[0] = bos_id
+        ids[1] = nxt
+        emb_dt = FN.cached_operand((emb,), dt)
+        plan = _StepPlan(dec, weights, cache, w_out, b_out, b_out16, emb_dt, ids, B, dt, dev, Smax)
         for t in range(1, steps):
-            if early_stop and t % sync_every == 0 and bool(finished.all()):    # :113 (checked every few steps)
+            if early_stop and t % sync_every == 0 and bool((ids[1: t + 1] == eos_id).any(0).all()):   # :113 (every few steps)
                 break
-            nxt = decode_step(nxt, P + t)
-            tokens[:, t + 1] = nxt
-            finished |= nxt == eos_id
+            plan.step(t, P + t)
             n_done = t + 1
+        tokens[:, 1: n_done + 1] = ids[1: n_done + 1].t()
     if was_training:
         model.train()
     return tokens[:, : n_done + 1]
