@@ -72,10 +72,10 @@ class GradBuckets:
                 p.grad = None
 
     def gather(self, b):
-        """Complete a bucket: copy in the gradients autograd left outside it, zero the slots that received nothing,
-        and point every .grad at its slot."""
+        """Complete a bucket (or a list of buckets, in ONE multi-tensor copy): copy in the gradients autograd left outside
+        it, zero the slots that received nothing, and point every .grad at its slot."""
         src, dst, zero = [], [], []
-        for p in b["params"]:
+        for p in (b["params"] if isinstance(b, dict) else [p for bb in b for p in bb["params"]]):
             g = p.grad
             if g is None:
                 zero.append(p._mm_view)
@@ -259,10 +259,19 @@ class DataParallel:
         (their bucket slots are zero), so every rank issues the same collectives in the same order."""
         if self._finished and self.collective:
             raise RuntimeError("DataParallel.finish() called twice without zero_grad(): the buckets are already reduced")
-        for b in self.buckets.buckets:
-            if not b.get("launched", False):
+        todo = [b for b in self.buckets.buckets if not b.get("launched", False)]
+        if todo and not self.collective and self.optimizer is None and todo[0]["flat"].is_cuda:
+            # one process, nothing to exchange or update per bucket: complete every bucket at once on the main stream.  (Per
+            # bucket on the side stream -- a wait, two small multi-tensor kernels and a join each -- the nine buckets of the
+            # config model cost 1.05 ms of cross-queue dependencies for 0.2 ms of copying at the end of every backward.)
+            FN.join_side_stream()
+            self.buckets.gather(todo)
+            for b in todo:
+                b["launched"] = True
+        else:
+            for b in todo:
                 self._launch(b)
-        FN.join_side_stream()
+            FN.join_side_stream()
         if self.collective:
             for b in self.buckets.buckets:
                 if not b.get("scaled", False):
