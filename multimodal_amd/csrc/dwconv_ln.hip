@@ -588,6 +588,7 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
 
     const int lend = l1 + 3;
     float gg[R][VEC], xh[R][VEC], ores[R][VEC], rsr[R];
+    float acc8[VEC], acc9[VEC];
     int grp = 0;
     for (int base = lw0; base < lend; base += RING) {
 #pragma unroll
@@ -622,12 +623,17 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
                 xh[r][v] = (a - mu) * rs;
                 gg[r][v] = gy[v] * g[v];
             }
-            if (own) {                                                   // uniform
-                float t8[VEC];
+            // parameter-gradient terms of the group's rows are summed in registers and added to the LDS partials ONCE per
+            // group: a read-modify-write of all 10 partial vectors per row made the LDS stores the bottleneck (1.3k cycles
+            // per row and workgroup: 0.25 of HBM on the wide shapes)
+            if (r == 0) {
 #pragma unroll
-                for (int v = 0; v < VEC; v++) t8[v] = gy[v] * xh[r][v];
-                padd(8, t8);
-                padd(9, gy);
+                for (int v = 0; v < VEC; v++) { acc8[v] = 0.f; acc9[v] = 0.f; }
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+                acc8[v] = own ? fmaf(gy[v], xh[r][v], acc8[v]) : acc8[v];
+                acc9[v] = own ? acc9[v] + gy[v] : acc9[v];
             }
             if (r != R - 1) continue;
             // ---- the group's 2 rows: both row sums with one barrier
@@ -660,16 +666,6 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
                     d[v] = cok ? rsr[rr] * (gg[rr][v] - m1[rr] - xh[rr][v] * m2[rr]) : 0.f;
                     dc[ii][v] = d[v];                       // dconv ring slot of row lr is ii (RING == unroll)
                 }
-                if (ownr) {                                 // uniform
-                    padd(7, d);
-#pragma unroll
-                    for (int t = 0; t < 7; t++) {
-                        float pw[VEC];
-#pragma unroll
-                        for (int v = 0; v < VEC; v++) pw[v] = d[v] * xw[(ii + t) % RING][v];
-                        padd(t, pw);
-                    }
-                }
                 // dx(lr-3) = sum_t w[t] * dconv(lr-t)
                 const int lo = lr - 3;
                 if (cok && lo >= l0 && lo < l1) {
@@ -682,6 +678,25 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
                         o[v] = a;
                     }
                     IO::store_nt(dxb + (long)lo * C + cidx, o);
+                }
+            }
+            {   // both rows' parameter terms (rows outside [l0, l1) contribute nothing), one LDS update per partial vector
+                const int i0 = i - 1, i1 = i;                // unroll indices of the group's rows (static; R == 2)
+                const int la = l - 1, lb = l;
+                const float oa = ((la >= l0) & (la < l1)) ? 1.f : 0.f, ob = ((lb >= l0) & (lb < l1)) ? 1.f : 0.f;   // uniform
+                if (oa + ob > 0.f) {
+                    float da[VEC], db_[VEC], acc[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) { da[v] = oa * dc[i0][v]; db_[v] = ob * dc[i1][v]; acc[v] = da[v] + db_[v]; }
+                    padd(7, acc);
+#pragma unroll
+                    for (int t = 0; t < 7; t++) {
+#pragma unroll
+                        for (int v = 0; v < VEC; v++) acc[v] = fmaf(da[v], xw[(i0 + t) % RING][v], db_[v] * xw[(i1 + t) % RING][v]);
+                        padd(t, acc);
+                    }
+                    padd(8, acc8);
+                    padd(9, acc9);
                 }
             }
         }
