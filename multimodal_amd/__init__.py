@@ -2,8 +2,9 @@
 KV-cached greedy decode, data-parallel training.  The path's own kernels -- depthwise conv + LayerNorm, the encoder's
 GEMMs with fused epilogues, prefix-LM / decode attention, LayerNorm, RoPE, relu^2, the fused optimizer, and the decoder
 products routed to the large-tile GEMM -- are hand-written HIP for gfx950 in libmmhip behind the C ABI of
-include/mmhip.h.  The remaining plain decoder GEMMs run on hipBLASLt through torch.mm, embedding gathers and the
-cross-entropy on ATen (DESIGN.md 1 lists exactly which).  There is no CPU or eager fallback for the libmmhip part."""
+include/mmhip.h.  By default the remaining plain decoder GEMMs run on hipBLASLt through torch.mm where it measured faster
+(set_gemm_backend("own") routes every product to libmmhip), embedding gathers and the cross-entropy on ATen (DESIGN.md 1
+lists exactly which).  There is no CPU or eager fallback for the libmmhip part."""
 import os as _os
 
 # hipBLASLt's GEMMs are stream-K kernels whose workgroups wait for each other's partial tiles; two of them launched from
@@ -13,5 +14,6 @@ import os as _os
 _os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")
 
 from .functional import compute_dtype, get_compute_dtype, set_compute_dtype  # noqa: F401
+from .functional import get_gemm_backend, set_gemm_backend  # noqa: F401
 
 __version__ = "0.1.0"

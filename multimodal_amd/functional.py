@@ -40,6 +40,26 @@ def compute_dtype(dtype):
         set_compute_dtype(prev)
 
 
+# Which kernels run the decoder's dense products.  "auto" (default): per product, whichever measured faster on MI355X -- the
+# library (hipBLASLt through torch.mm/addmm) for the short-K products (q/k/v, d_model -> d_ffn, their dX at N = d_ffn, all
+# weight gradients), libmmhip for the N = d_model products with their fused epilogues (DESIGN.md 4 has the table).  "own":
+# EVERY product on libmmhip (large-tile kernel for K-contiguous operands, gemm_k's transposed-read tiles for the weight
+# gradients, relu^2 and its derivative in GEMM epilogues): the complete hot path without the library, kept tested and timed
+# (bench.py: train_own_gemms) so that the per-product choice stays a measured one.
+_gemm_backend = os.environ.get("MM_GEMM_BACKEND", "auto")
+
+
+def set_gemm_backend(name: str) -> None:
+    global _gemm_backend
+    if name not in ("auto", "own"):
+        raise ValueError("gemm backend must be 'auto' or 'own'")
+    _gemm_backend = name
+
+
+def get_gemm_backend() -> str:
+    return _gemm_backend
+
+
 def _w(p: Tensor, dtype) -> Tensor:
     """GEMM operand copy of a float32 master weight in the compute dtype."""
     p = p.detach()
@@ -263,6 +283,34 @@ class LayerNorm(torch.autograd.Function):
         return dx, dw, db
 
 
+class Linear(torch.autograd.Function):
+    """x W^T + b on libmmhip for the "own" GEMM backend (final `out` projection transformer_decoder.py:307, memory_proj
+    :259): forward with the bias in the epilogue, dX on the transposed operand copy, dW through _weight_grad, db a column sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        dt = x.dtype
+        K, N = w.shape[1], w.shape[0]
+        x2 = x.reshape(-1, K).contiguous()
+        y = ops.gemm(x2, cached_operand((w,), dt), x2.shape[0], N, K, bias=b.detach())
+        ctx.save_for_backward(x2, w)
+        ctx.b = b
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dt = x2.dtype
+        K, N = w.shape[1], w.shape[0]
+        dy2 = dy.reshape(-1, N).contiguous()
+        M = dy2.shape[0]
+        dx = ops.gemm(dy2, cached_operand((w,), dt, transpose=True), M, K, N).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        db = ops.colsum(dy2, M, N)
+        dw = _weight_grad(w, dy2, x2)
+        return dx, dw, db
+
+
 class Embedding(torch.autograd.Function):
     """nn.Embedding lookup in the compute dtype (models/transformer_decoder.py:256,:272).  Backward: the weight gradient
     is onehot(idx)^T . dY as ONE library GEMM (exact products, float32 sums, deterministic) instead of ATen's sort-based
@@ -381,7 +429,14 @@ def shadows_written(params) -> None:
 
 
 def _mm_f32(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
-    """a @ b with a float32 result (bf16 operands accumulate and land in f32: weight gradients never see bf16)."""
+    """a @ b with a float32 result (bf16 operands accumulate and land in f32: weight gradients never see bf16).
+    Called as _mm_f32(dy2.t(), x2): the weight-gradient product dW[n][k] = sum_m dy2[m][n] x2[m][k]."""
+    if _gemm_backend == "own":
+        dy2 = a.t()                               # [rows, n] with unit inner stride again
+        n, k, rows = dy2.shape[1], b.shape[1], b.shape[0]
+        tag = "gemm_side" if torch.cuda.current_stream(b.device) == _side_streams.get(b.device) else "gemm"
+        return ops.gemm(dy2, b, n, k, rows, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, out=out,
+                        split_k=_split_k(n, k, rows), ws_tag=tag)
     if a.dtype == torch.float32:
         return torch.mm(a, b, out=out) if out is not None else torch.mm(a, b)
     if out is not None:
@@ -393,7 +448,7 @@ def _linear_res(x2: Tensor, w: Tensor, b: Tensor, res: Tensor) -> Tensor:
     """res + x2 W^T + b.  bf16: the large-tile libmmhip GEMM with bias and residual fused in its epilogue (these are
     the N = d_model products, where its tile choice beats the library's); f32: library GEMM + in-place add."""
     dt = x2.dtype
-    if dt == torch.bfloat16:
+    if dt == torch.bfloat16 or _gemm_backend == "own":
         return ops.gemm(x2, cached_operand((w,), dt), x2.shape[0], w.shape[0], w.shape[1], bias=b.detach(), res=res)
     return torch.addmm(b.detach(), x2, w.detach().t()).add_(res)
 
@@ -468,15 +523,24 @@ class DecoderLayer(torch.autograd.Function):
         train = any(ctx.needs_input_grad)
         x = x.contiguous()
         xa, mean1, rstd1 = ops.layernorm_fwd(x, ln1w.detach(), ln1b.detach(), save_stats=train)
-        qkv = torch.addmm(cached_operand((qb, kb, vb), dt), xa.view(M, D), cached_operand((qw, kw, vw), dt).t())
+        own = _gemm_backend == "own"
+        if own:
+            qkv = ops.gemm(xa.view(M, D), cached_operand((qw, kw, vw), dt), M, 3 * D, D,
+                           bias=cached_operand((qb, kb, vb), torch.float32))
+        else:
+            qkv = torch.addmm(cached_operand((qb, kb, vb), dt), xa.view(M, D), cached_operand((qw, kw, vw), dt).t())
         qkv = qkv.view(B, S, 3, D)
         ops.rope_inplace(qkv.view(B, S, 3 * D)[:, :, :2 * D], 2 * H, rot, cos_t, sin_t)      # q and k in one launch
         o, lse = ops.prefix_attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], H, 0, prompt_len, cos_t, sin_t, stablemax,
                                      save_lse=train)
         x1 = _linear_res(o.view(M, D), ow, ob, x.view(M, D))
         xf, mean2, rstd2 = ops.layernorm_fwd(x1, ln2w.detach(), ln2b.detach(), save_stats=train)
-        h = torch.addmm(cached_operand((b1,), dt), xf, cached_operand((w1,), dt).t())
-        a = ops.relu2_fwd(h)
+        if own:                               # bias, the saved pre-activation and relu^2 in the product's epilogue
+            h = torch.empty((M, w1.shape[0]), dtype=dt, device=x.device)
+            a = ops.gemm(xf, cached_operand((w1,), dt), M, w1.shape[0], D, bias=b1.detach(), pre=h, act=ops.ACT_RELU2)
+        else:
+            h = torch.addmm(cached_operand((b1,), dt), xf, cached_operand((w1,), dt).t())
+            a = ops.relu2_fwd(h)
         out = _linear_res(a, w2, b2, x1)
         if train:
             ctx.save_for_backward(x, mean1, rstd1, xa, qkv, o, lse, x1, mean2, rstd2, xf, h, a, cos_t, sin_t,
@@ -497,19 +561,24 @@ class DecoderLayer(torch.autograd.Function):
         F4 = h.shape[1]
         dout = dout.contiguous().view(M, D)
         # ---- the dX chain (critical path)
-        if dt == torch.bfloat16:
-            # dh = dout . W2 with W2 [d_model][d_ffn]: as written the library runs an NN product (reduction index strided in
-            # W2) at 0.37 PF/s (553 us at the config batch); on a transposed operand copy it is an NT product at 1.0 PF/s
-            dh = torch.mm(dout, cached_operand((w2,), dt, transpose=True).t())
-        else:
-            dh = torch.mm(dout, w2.detach())
+        own = _gemm_backend == "own"
         esz = 2 if dt == torch.bfloat16 else 4
-        if (F4 * esz) % 16 == 0:
-            _, db1 = ops.relu2_bwd_colsum_(h, dh)                 # bias gradient of ffn_w1 in the same pass
-        else:
-            ops.relu2_bwd_(h, dh)
+        if own:                          # the relu^2 derivative in the product's epilogue; the bias gradient is a column sum
+            dh = ops.gemm(dout, cached_operand((w2,), dt, transpose=True), M, F4, D, mul=h, act=ops.ACT_RELU2)
             db1 = None
-        if dt == torch.bfloat16:         # N = d_model, K = d_ffn: NT product on the transposed operand copy
+        else:
+            if dt == torch.bfloat16:
+                # dh = dout . W2 with W2 [d_model][d_ffn]: as written the library runs an NN product (reduction index strided
+                # in W2) at 0.37 PF/s (553 us at the config batch); on a transposed operand copy it is an NT product at 1.0 PF/s
+                dh = torch.mm(dout, cached_operand((w2,), dt, transpose=True).t())
+            else:
+                dh = torch.mm(dout, w2.detach())
+            if (F4 * esz) % 16 == 0:
+                _, db1 = ops.relu2_bwd_colsum_(h, dh)                 # bias gradient of ffn_w1 in the same pass
+            else:
+                ops.relu2_bwd_(h, dh)
+                db1 = None
+        if dt == torch.bfloat16 or own:  # N = d_model, K = d_ffn: NT product on the transposed operand copy
             dxf = ops.gemm(dh, cached_operand((w1,), dt, transpose=True), M, D, F4)
         else:
             dxf = torch.mm(dh, w1.detach())
@@ -519,7 +588,10 @@ class DecoderLayer(torch.autograd.Function):
         else:
             dx1, dln2w, dln2b = ops.layernorm_bwd(x1, dxf, dout, ln2w.detach(), mean2, rstd2)  # + residual gradient
             db2 = dbo = None
-        d_o = torch.mm(dx1, cached_operand((ow,), dt)).view(B, S, D)
+        if own:
+            d_o = ops.gemm(dx1, cached_operand((ow,), dt, transpose=True), M, D, D).view(B, S, D)
+        else:
+            d_o = torch.mm(dx1, cached_operand((ow,), dt)).view(B, S, D)
         dqkv = ops.prefix_attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, d_o, lse, H, 0, prompt_len, cos_t, sin_t,
                                    stablemax)                                               # saved q,k are rotated
         ops.rope_inplace(dqkv.view(B, S, 3 * D)[:, :, :2 * D], 2 * H, rot, cos_t, sin_t, inverse=True)
@@ -527,7 +599,7 @@ class DecoderLayer(torch.autograd.Function):
         xa2 = xa.view(M, D)
         # last use of this layer's weights: issued before the parameter gradients, because their completion may trigger
         # the optimizer update of these very weights (dp.DataParallel.attach_optimizer)
-        if dt == torch.bfloat16:         # N = d_model: NT product on the transposed stacked copy (large-tile kernel)
+        if dt == torch.bfloat16 or own:  # N = d_model: NT product on the transposed stacked copy (large-tile kernel)
             dxa = ops.gemm(dqkv2, cached_operand((qw, kw, vw), dt, transpose=True), M, D, 3 * D)
         else:
             dxa = torch.mm(dqkv2, cached_operand((qw, kw, vw), dt))

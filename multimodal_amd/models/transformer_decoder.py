@@ -48,6 +48,8 @@ def stablemax(x, dim=-1, clamp_val=20.0, epsilon=1e-9):
 
 
 def _lin(x, lin, dt):
+    if FN.get_gemm_backend() == "own":
+        return FN.Linear.apply(x.to(dt), lin.weight, lin.bias)
     return F.linear(x, lin.weight.to(dt), lin.bias.to(dt))
 
 
