@@ -265,6 +265,8 @@ static void launch_tile(GemmP& p, int akm, int bkm, int splits, hipStream_t st) 
 
 bool gemm_big_applicable(const GemmP& p, int dtype, int a_kmajor, int b_kmajor, int splits);
 int gemm_big_launch(GemmP& p, int out_dtype, hipStream_t st, void* ws, size_t ws_bytes);
+bool gemm_big_tn_applicable(const GemmP& p, int dtype, int a_kmajor, int b_kmajor, int splits);
+int gemm_big_tn_launch(GemmP& p, int out_dtype, hipStream_t st, void* ws, size_t ws_bytes);
 
 extern "C" int mm_gemm(const mm_gemm_args* a, void* stream) {
     MM_CHECK(a && a->A && a->B && a->out, "gemm: null pointer");
@@ -307,6 +309,10 @@ extern "C" int mm_gemm(const mm_gemm_args* a, void* stream) {
     // split_k <= 1 with a workspace given: the large-tile path may split K on its own for skinny, deep-K problems
     if (!no256 && gemm_big_applicable(p, a->dtype, a->a_kmajor, a->b_kmajor, splits))
         return gemm_big_launch(p, a->out_dtype, st, splits <= 1 ? a->workspace : nullptr, splits <= 1 ? a->workspace_bytes : 0);
+    // weight-gradient form (both operands K-major): the large-tile kernel with its own K split when the caller left one open
+    if (!no256 && !a->pre && !a->mul && !a->act && !a->gamma && !a->rowscale && !a->res &&
+        gemm_big_tn_applicable(p, a->dtype, a->a_kmajor, a->b_kmajor, splits))
+        return gemm_big_tn_launch(p, a->out_dtype, st, a->workspace, a->workspace_bytes);
     if (a->dtype == MM_BF16) {
         if (a->out_dtype == MM_BF16) launch_tile<bf16, bf16>(p, a->a_kmajor, a->b_kmajor, splits, st);
         else launch_tile<bf16, float>(p, a->a_kmajor, a->b_kmajor, splits, st);

@@ -311,6 +311,143 @@ int launch_big(const GemmP& p, hipStream_t st, int splits = 1) {
     return MM_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Weight-gradient form:  out[M][N] = sum_k A[k][M] . B[k][N]  -- BOTH operands K-major (dW = dY^T X: the reduction runs over
+// the tokens, the slow index of both tensors).  Same skeleton as gemm_big_k (8 waves 2 x 4, 64-deep K steps, operands global
+// -> LDS by DMA into two stages, one barrier per step, epilogue through per-wave LDS windows), with
+//   * LDS image [64 k-rows][BM | BN columns]: a DMA piece (1 KiB) is linear in LDS, each lane's SOURCE address is the one its
+//     16 bytes belong to; k-rows past K read a zero page, columns past M / N are clamped (never stored);
+//   * fragments by ds_read_b64_tr_b16 (hardware transpose: a lane gets 4 consecutive k of one column); the 8 k-rows x 32 bytes
+//     of a half-wave read must fall in 8 different 32-byte bank groups: the 32-byte chunk index of a row is XOR-ed with a
+//     function of the row (3 bits for a 512-byte row pitch, 2 bits for 640 bytes: the pitch itself already alternates);
+//   * deep K, few tiles: K is split over blockIdx.y by the host so that one round of workgroups covers the chip; the raw f32
+//     slabs are summed in a fixed order by big_splitk_epilogue_k (deterministic).
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned g_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+template <int BX> __device__ __forceinline__ int tn_swz(int row) {          // BX columns: row pitch 2*BX bytes
+    if constexpr ((BX / 16) % 8 == 0) return (row & 3) | (((row >> 3) & 1) << 2);
+    else { static_assert((BX / 16) % 8 == 4, "unsupported pitch"); return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+}
+
+template <typename TO, int TM, int TN, int WN>
+__global__ __launch_bounds__(128 * WN, 1) void gemm_big_tn_k(const GemmP p) {
+    typedef BigTile<TM, TN, WN> G;
+    constexpr int BM = G::BM, BN = G::BN;
+    constexpr int A_BYTES = BK * BM * 2, PA = 2 * BM, PB = 2 * BN;             // row pitches in bytes
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int kt0 = p.partial ? blockIdx.y * (p.k_per_split / BK) : 0;
+    const int ksteps = (p.K + BK - 1) / BK;
+    const int nk = p.partial ? min(ksteps - kt0, p.k_per_split / BK) : ksteps;
+    const int nwg = p.tiles_m * p.tiles_n;
+    long m0, n0;
+    {
+        const int id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        m0 = (long)(wg / p.tiles_n) * BM; n0 = (long)(wg % p.tiles_n) * BN;
+    }
+    // ---- staging: piece q = wave + NW*i covers bytes [1024 q, 1024 q + 1024) of the stage image [A rows | B rows]
+    const bf16* src[G::PPW];
+    int srow[G::PPW];
+#pragma unroll
+    for (int i = 0; i < G::PPW; i++) {
+        const int q = wave + G::NW * i;
+        int off = q * 1024 + lane * 16;
+        const bool isA = off < A_BYTES;
+        if (!isA) off -= A_BYTES;
+        const int pitch = isA ? PA : PB;
+        const int row = off / pitch, c16 = (off % pitch) >> 4;
+        const int sw = isA ? tn_swz<BM>(row) : tn_swz<BN>(row);
+        const int lc16 = (((c16 >> 1) ^ sw) << 1) | (c16 & 1);               // logical 16-byte chunk held at this LDS place
+        long col = (isA ? m0 : n0) + lc16 * 8;
+        const long lim = (isA ? p.M : p.N) - 8;
+        if (col > lim) col = lim;
+        src[i] = (isA ? (const bf16*)p.A + col : (const bf16*)p.B + col) + (long)(kt0 * BK + row) * (isA ? p.lda : p.ldb);
+        srow[i] = kt0 * BK + row;
+    }
+    auto stage = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * G::STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < G::PPW; i++) {
+            const int q = wave + G::NW * i;
+            if (q < G::PIECES) {                                             // wave-uniform
+                const bool isA = q * 1024 < A_BYTES;                          // pieces do not straddle A | B (A_BYTES % 1024 == 0)
+                const bf16* s = src[i] + (long)kt * BK * (isA ? p.lda : p.ldb);
+                if (srow[i] + kt * BK >= p.K) s = reinterpret_cast<const bf16*>(g_zero_page);
+                __builtin_amdgcn_global_load_lds((glb_vp)s, (lds_vp)(base + q * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // ---- fragment read offsets: lane (fr, fg) reads k-rows fg*8 + qq (+4) of a 32-row half step, 8 bytes at column 4*pp
+    const int fr = lane & 15, fg = lane >> 4, qq = fr >> 2, pp = fr & 3;
+    // both reads of a fragment (rows r and r+4) share the swizzle value (it ignores bit 2 of the row), as do the two half steps
+    const int swA = tn_swz<BM>(fg * 8 + qq), swB = tn_swz<BN>(fg * 8 + qq);
+    const int rowoff_a = (fg * 8 + qq) * PA + pp * 8, rowoff_b = A_BYTES + (fg * 8 + qq) * PB + pp * 8;
+    const int cbase_a = wr * (BM / 32), cbase_b = wc * (BN / WN / 16);          // first 32-byte column chunk of the wave's tile
+
+    stage(0, 0);
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    typedef bf16x4_t __attribute__((address_space(3))) * lds4p;
+    for (int kt = 0; kt < nk; kt++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const unsigned char* ls = smem + (kt & 1) * G::STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const unsigned char* a0 = ls + rowoff_b + ks * 32 * PB + (((cbase_b + j) ^ swB) << 5);
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(a0));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(a0 + 4 * PB));
+                fb[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const unsigned char* a0 = ls + rowoff_a + ks * 32 * PA + (((cbase_a + i) ^ swA) << 5);
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(a0));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(a0 + 4 * PA));
+                fa[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    big_epilogue<TO, TM, TN, G::EPI_ROW>(p, acc, smem + G::STAGE_BYTES + wave * G::EPI_WAVE, m0 + wr * (BM / 2), n0 + wc * (BN / WN), lane);
+}
+
+template <typename TO, int TM, int TN>
+int launch_big_tn(const GemmP& p, hipStream_t st, int splits) {
+    typedef BigTile<TM, TN, 4> G;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_big_tn_k<TO, TM, TN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) MM_FAIL(MM_ERR_LAUNCH, "gemm_big_tn: cannot raise dynamic LDS to %d bytes: %s", G::LDS_BYTES, hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int tiles = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL((gemm_big_tn_k<TO, TM, TN, 4>), dim3((unsigned)tiles, (unsigned)splits), dim3(512), G::LDS_BYTES, st, p);
+    MM_LAUNCH_CHECK();
+    if (p.partial) {
+        const long nq = (long)p.M * ((p.N + 3) / 4);
+        hipLaunchKernelGGL(big_splitk_epilogue_k<TO>, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, st, p, splits);
+        MM_LAUNCH_CHECK();
+    }
+    return MM_OK;
+}
+
 struct Shape { int tm, tn, wn; };
 // 8-wave shapes (256x256 class) for problems that fill the chip with them, 4-wave shapes (128x128, 64x128; two or three
 // workgroups per CU) for skinny problems -- M of about 1000 rows: the encoder's stage-3 products at the config batch and the
@@ -396,6 +533,58 @@ int gemm_big_launch(GemmP& p, int out_dtype, hipStream_t st, void* ws, size_t ws
         case 3: GO_(7, 5, 4);
         case 4: GO_(4, 4, 2);
         default: GO_(2, 4, 2);
+    }
+#undef GO_
+}
+
+// ---- weight-gradient form (both operands K-major): applicability, shape / split choice, launch
+bool gemm_big_tn_applicable(const GemmP& p, int dtype, int a_kmajor, int b_kmajor, int splits) {
+    static const bool off = getenv("MM_GEMM_NO_TN") != nullptr;              // A/B switch
+    if (off || dtype != MM_BF16 || !a_kmajor || !b_kmajor || splits > 1 || p.partial) return false;
+    if (!p.a_vec || !p.b_vec || p.M % 8 || p.N % 8 || p.M < 256 || p.N < 256 || p.K < 1024) return false;
+    return (long)p.M * p.N >= 256L * 256 * 12;
+}
+
+int gemm_big_tn_launch(GemmP& p, int out_dtype, hipStream_t st, void* ws, size_t ws_bytes) {
+    const int osz = out_dtype == MM_BF16 ? 2 : 4;
+    auto al = [&](const void* q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
+    p.o_vec = (p.ldo * osz) % 16 == 0 && al(p.out) && al(p.pre) && al(p.mul) && al(p.res);
+    struct Cand { int tm, tn; };
+    static const Cand cands[3] = {{8, 4}, {8, 5}, {10, 4}};                   // 256x256, 256x320, 320x256
+    const long ksteps = cdiv(p.K, BK);
+    double best_cost = 1e30; int best = 0, best_sp = 1;
+    static const char* fshape = getenv("MM_GEMM_TN_SHAPE");
+    static const char* fsplit = getenv("MM_GEMM_TN_SPLITS");
+    for (int c = 0; c < 3; c++) {
+        if (fshape && atoi(fshape) != c) continue;
+        const long tiles = cdiv(p.M, 32 * cands[c].tm) * cdiv(p.N, 64 * cands[c].tn);
+        static const double kStepUs[3] = {2.1, 2.5, 2.4};                     // measured us per K step of each shape
+        for (int sp = 1; sp <= 8; sp++) {
+            if (fsplit && atoi(fsplit) != sp) continue;
+            if (sp > 1 && ((size_t)sp * p.M * p.N * sizeof(float) > ws_bytes || ksteps / sp < 8)) continue;
+            const long rounds = cdiv(tiles * sp, kNumCU);
+            double cost = rounds * (cdiv(ksteps, sp) * kStepUs[c] + 9.0);
+            if (sp > 1) cost += 5.0 + (double)(sp + 1) * p.M * p.N * 4.0 / 4.5e6;   // slab writes are in the tile time; the reduce pass
+            if (cost < best_cost) { best_cost = cost; best = c; best_sp = sp; }
+        }
+    }
+    if (best_cost > 1e29) MM_FAIL(MM_ERR_ARG, "gemm_big_tn: no admissible shape / split");
+    (void)ws;
+    const Cand s = cands[best];
+    p.tiles_m = (int)cdiv(p.M, 32 * s.tm); p.tiles_n = (int)cdiv(p.N, 64 * s.tn);
+    int splits = best_sp;
+    if (splits > 1) {
+        const int steps = (int)cdiv(ksteps, splits);
+        p.k_per_split = steps * BK;
+        splits = (int)cdiv(ksteps, steps);
+        p.partial = splits > 1 ? (float*)ws : nullptr;
+    }
+    if (splits <= 1) { splits = 1; p.partial = nullptr; p.k_per_split = (int)(ksteps * BK); }
+#define GO_(TM_, TN_) return out_dtype == MM_BF16 ? launch_big_tn<bf16, TM_, TN_>(p, st, splits) : launch_big_tn<float, TM_, TN_>(p, st, splits)
+    switch (best) {
+        case 0: GO_(8, 4);
+        case 1: GO_(8, 5);
+        default: GO_(10, 4);
     }
 #undef GO_
 }

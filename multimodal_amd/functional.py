@@ -428,10 +428,18 @@ def shadows_written(params) -> None:
             _operand_cache[key] = (tuple((q._version, q.data_ptr()) for q in ps), ent[1], ent[2])
 
 
+_DW_SMALL_OWN = os.environ.get("MM_DW_SMALL_OWN", "0") == "1"
+
+
 def _mm_f32(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """a @ b with a float32 result (bf16 operands accumulate and land in f32: weight gradients never see bf16).
     Called as _mm_f32(dy2.t(), x2): the weight-gradient product dW[n][k] = sum_m dy2[m][n] x2[m][k]."""
-    if _gemm_backend == "own":
+    # "auto": the library.  MM_DW_SMALL_OWN=1 sends small outputs under a long reduction (the square out-projection: 49 tiles
+    # of 256 x 256) to the large-tile weight-gradient kernel, which splits K over the chip: 81 vs 102 us alone, but INSIDE the
+    # step its 250 512-thread workgroups crowd the main stream's kernels (25.70 vs 25.49 ms per step, three A/B pairs): off.
+    small = _DW_SMALL_OWN and a.dtype == torch.bfloat16 and a.shape[0] * b.shape[1] <= (1 << 22) and b.shape[0] >= 4096 and \
+        a.shape[0] >= 256 and b.shape[1] >= 256 and a.shape[0] % 8 == 0 and b.shape[1] % 8 == 0
+    if _gemm_backend == "own" or small:
         dy2 = a.t()                               # [rows, n] with unit inner stride again
         n, k, rows = dy2.shape[1], b.shape[1], b.shape[0]
         tag = "gemm_side" if torch.cuda.current_stream(b.device) == _side_streams.get(b.device) else "gemm"

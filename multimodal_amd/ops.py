@@ -230,6 +230,11 @@ def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool = False
         nbytes = 8 * M * N * 4
         ws = workspace(nbytes, A.device, ws_tag + "_auto")
         a.workspace, a.workspace_bytes = L.ptr(ws), nbytes
+    elif a_kmajor and b_kmajor and A.dtype == torch.bfloat16 and M >= 256 and N >= 256 and K >= 1024 and M * N >= 786432:
+        # weight-gradient form on the large-tile kernel: it splits K itself (few tiles, deep reduction); up to 8 slabs, 256 MiB
+        nbytes = max(1, min(8, (256 << 20) // (M * N * 4))) * M * N * 4
+        ws = workspace(nbytes, A.device, ws_tag + "_tn")
+        a.workspace, a.workspace_bytes = L.ptr(ws), nbytes
     L.check(L.lib().mm_gemm(C.byref(a), L.cur_stream()), "mm_gemm")
     return out
 

@@ -280,6 +280,29 @@ def test_gemm_large_tile(M, N, K):
     assert rel_err(out.float().cpu(), ref.float() * 2 * F.relu(hp.float())) < TOL[torch.bfloat16]
 
 
+@pytest.mark.parametrize("M,N,K", [(1600, 1600, 10080), (1288, 648, 1100), (512, 2568, 2048), (6400, 1600, 4128)])
+def test_gemm_large_tile_weight_gradient_form(M, N, K, monkeypatch):
+    """Both operands K-major (dW = dY^T X) on the large-tile kernel: K not a multiple of 64 (zero page), ragged M / N
+    (multiples of 8), every tile shape, with and without its K split, float32 and bf16 results; exact products of bf16 operands."""
+    from multimodal_amd import ops
+    d = _dev()
+    a = _rand(K, M, seed=1).to(torch.bfloat16); b = _rand(K, N, seed=2, scale=0.3).to(torch.bfloat16)
+    ref = a.double().t() @ b.double()
+    scale = (a.double().abs().t() @ b.double().abs()).max().item()
+    ad, bd = a.to(d), b.to(d)
+    out = ops.gemm(ad, bd, M, N, K, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+    assert (out.double().cpu() - ref).abs().max().item() <= 4e-6 * scale
+    out2 = ops.gemm(ad, bd, M, N, K, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+    assert torch.equal(out, out2)                                   # fixed-order slab sums: deterministic
+    out16 = ops.gemm(ad, bd, M, N, K, a_kmajor=True, b_kmajor=True)
+    assert rel_err(out16.float().cpu(), ref.float()) < TOL[torch.bfloat16]
+    # a strided column slice as the A operand (the per-projection weight gradients of a fused q/k/v gradient tensor)
+    wide = torch.zeros(K, M + 64, dtype=torch.bfloat16, device=d)
+    wide[:, 32: 32 + M] = ad
+    out3 = ops.gemm(wide[:, 32: 32 + M], bd, M, N, K, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+    assert (out3.double().cpu() - ref).abs().max().item() <= 4e-6 * scale
+
+
 def test_cast_transpose_and_relu2():
     from multimodal_amd import ops
     d = _dev()
