@@ -20,7 +20,11 @@
 #include <algorithm>
 #include <type_traits>
 
+#ifndef GEMM_BIG_STAGGER
+#define GEMM_BIG_STAGGER 1
+#endif
 namespace {
+constexpr bool STAGGER = GEMM_BIG_STAGGER != 0;
 constexpr int BK = 64;
 constexpr int kNumCU = 256;
 typedef __attribute__((address_space(3))) void* lds_vp;
@@ -244,26 +248,46 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_k(const GemmP p) {
 #pragma unroll
             for (int j = 0; j < TN; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-        for (int kt = 0; kt < nk; kt++) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                               // K tile kt landed; everyone is done with the other stage
-            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-            const unsigned char* ls = smem + (kt & 1) * G::STAGE_BYTES;
-            {
+        // The two waves that share a SIMD (w and w + NW/2) run half a K step apart: in lockstep all eight waves read their
+        // fragments (192 KiB per step: ~0.37 us of LDS time) and THEN all multiply (~1 us), the step time was the sum of the
+        // two; staggered, one wave's fragment reads sit under its partner's MFMAs.  The late half keeps the fragments of a
+        // tile's second half step in registers across the barrier (read before the stage is handed back to the DMA).
+        bf16x8_t fa[TM], fb[TN];
+        auto rd = [&](const unsigned char* ls, int ks) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ks++) {
-                    bf16x8_t fa[TM], fb[TN];
+            for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const bf16x8_t*>(ls + offB[ks] + j * 2048);
 #pragma unroll
-                    for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const bf16x8_t*>(ls + offB[ks] + j * 2048);
+            for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const bf16x8_t*>(ls + offA[ks] + i * 2048);
+        };
+        auto mm = [&]() {
 #pragma unroll
-                    for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const bf16x8_t*>(ls + offA[ks] + i * 2048);
+            for (int i = 0; i < TM; i++)
 #pragma unroll
-                    for (int i = 0; i < TM; i++)
-#pragma unroll
-                        for (int j = 0; j < TN; j++)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        };
+        const bool late = STAGGER && p.stagger && __builtin_amdgcn_readfirstlane(wave) >= G::NW / 2;       // scalar
+        if (!late) {
+            for (int kt = 0; kt < nk; kt++) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                           // K tile kt landed; everyone is done with the other stage
+                if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+                const unsigned char* ls = smem + (kt & 1) * G::STAGE_BYTES;
+                rd(ls, 0); mm();
+                rd(ls, 1); mm();
             }
+        } else {
+            for (int kt = 0; kt < nk; kt++) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+                const unsigned char* ls = smem + (kt & 1) * G::STAGE_BYTES;
+                if (kt > 0) mm();                          // second half step of tile kt-1 (fragments held in registers)
+                rd(ls, 0); mm();
+                rd(ls, 1);                                 // held across the next barrier
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // in registers before the stage can be overwritten
+            }
+            if (nk > 0) mm();
         }
         __syncthreads();                                   // every wave is done with both operand stages
         big_epilogue<TO, TM, TN, G::EPI_ROW>(p, acc, smem + G::STAGE_BYTES + wave * G::EPI_WAVE, m0 + wr * (BM / 2), n0 + wc * (BN / WN), lane);
@@ -514,6 +538,8 @@ int gemm_big_launch(GemmP& p, int out_dtype, hipStream_t st, void* ws, size_t ws
         for (int i = 1; i < kNumShapes; i++)
             if (shape_cost(p, kShapes[i], ws != nullptr) < shape_cost(p, kShapes[best], ws != nullptr) * 0.97) best = i;
     const Shape s = kShapes[best];
+    static const char* fstag = getenv("MM_GEMM_BIG_STAGGER");            // "0" / "1": benchmark override
+    p.stagger = fstag ? atoi(fstag) : 1;                          // measured: 1-3 % on every routed shape
     p.tiles_m = (int)cdiv(p.M, 32 * s.tm); p.tiles_n = (int)cdiv(p.N, 16 * s.tn * s.wn);
     static const char* fsp = getenv("MM_GEMM_BIG_SPLITS");               // benchmark override
     int splits = ws ? (fsp ? atoi(fsp) : pick_splits(p, s, ws_bytes)) : 1;

@@ -14,6 +14,7 @@ struct GemmP {
     int k_per_split;               // K range per blockIdx.z
     float* partial;                // split-K slabs [z][M][N] (f32) or NULL
     int tiles_m, tiles_n;
+    int stagger;                   // large-tile kernel: the two waves of a SIMD run half a K step apart
 };
 
 __device__ __forceinline__ float act_fwd(int act, float v) {
