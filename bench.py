@@ -27,9 +27,9 @@ CONFIGS = {
     "test_config": dict(E=768, H=4, L=8, sm=True, max_seq=95, max_nmr=190, max_mem=32),
     "real_config_mup": dict(E=2048, H=4, L=8, sm=True, max_seq=95, max_nmr=190, max_mem=32),
 }
-K1_PMC = os.path.join("profiles", "r01_k1_pmc.json")
-K4_PMC = os.path.join("profiles", "r01_k4_pmc.json")
-ATTN_PMC = os.path.join("profiles", "r02_attn_pmc.json")
+K1_PMC = os.path.join("profiles", "r02_k1_pmc.json")
+K4_PMC = os.path.join("profiles", "r02_k4_pmc.json")
+ATTN_PMC = os.path.join("profiles", "r02_attn3_pmc.json")
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide)
 
@@ -184,7 +184,8 @@ def k2_roofline(device, C=1600, Ln=31):
 def attn_roofline(device, B=32, H=16, d=100, N=190, T=94):
     """K3 / K3b at the local_config shape (S = 31+N+T = 315, prompt 221, stablemax, bf16, q/k pre-rotated as in the
     model): SURVEY 8d flops 4*B*S^2*E forward, 2.5x that backward (mask sparsity not discounted), against the dense bf16
-    MFMA peak.  The stablemax arithmetic makes these kernels VALU-bound, so the fraction is far from 1 by construction."""
+    MFMA peak.  Per score the stablemax weight costs 5-6 vector instructions against 2 MFMAs' worth of matrix work per 64 scores,
+    so vector issue, not the matrix cores, bounds these kernels (counters: profiles/r02_attn3_pmc.json)."""
     from multimodal_amd import ops
     E, S, P = H * d, 31 + N + T, 31 + N
     rot = int(d * 0.5)
@@ -206,7 +207,7 @@ def attn_roofline(device, B=32, H=16, d=100, N=190, T=94):
         counters = {"source": ATTN_PMC + " (not re-measured in this run)"}
         for kname, e in pm.items():
             counters[kname] = {k: v for k, v in e.items() if k != "counters_per_launch" and k != "kernel_name"}
-    return {"counters": counters, "kernel": "prefix_attn_fwd2_k / prefix_attn_bwd_dq5_k + _dkv5_k", "bound": "mfma", "unit": "TFLOP/s",
+    return {"counters": counters, "kernel": "attn_fwd3_k / attn_delta_k + attn_bwd_dq3_k + attn_bwd_dkv3_k", "bound": "mfma", "unit": "TFLOP/s",
             "peak": MFMA_BF16_PEAK_TFLOPS, "achieved": round(af, 1), "frac": round(af / MFMA_BF16_PEAK_TFLOPS, 4),
             "launch_us": round(tf * 1e6, 1), "bwd_achieved": round(ab, 1), "bwd_frac": round(ab / MFMA_BF16_PEAK_TFLOPS, 4),
             "bwd_launch_us": round(tb * 1e6, 1), "traffic": None,
@@ -282,15 +283,18 @@ def greedy_bench(device, world, rank):
                                      "frac": round(ach / HBM_PEAK_GBPS, 4), "ms_per_decode_step": round(t_loop / n_dec * 1e3, 4),
                                      "kv_bytes_per_step_avg": kv // n_dec, "weight_bytes_per_step": wts // n_dec,
                                      "note": "K4 (the KV read) is about half of the step at 0.61-0.64 of HBM; the rest is "
-                                             "16 short latency-bound GEMMs (M = batch rows), LayerNorm and launch gaps"}}
+                                             "16 short latency-bound GEMMs (M = batch rows) and LayerNorm; the step is issued "
+                                             "from prepared launches (0.18 ms of host time per step): GPU-bound"}}
 
 
-def train_leg(c, device, batch, dtype, steps, warmup, rank=0):
+def train_leg(c, device, batch, dtype, steps, warmup, rank=0, backend="auto"):
     """Extra single-rank measurement of the same train step at another per-GPU batch / compute dtype (SURVEY 8d:
     report the config batch and a saturating batch, bf16 and fp32)."""
     import multimodal_amd as mm
     from multimodal_amd.dp import DataParallel
     from multimodal_amd.optim import OrthoGradAdamW
+    prev_backend = mm.get_gemm_backend()
+    mm.set_gemm_backend(backend)           # "own": every dense product on libmmhip (no library GEMM on the path)
     with mm.compute_dtype(dtype):
         model = build_model(c, device).train()
         dp = DataParallel(model)
@@ -315,8 +319,9 @@ def train_leg(c, device, batch, dtype, steps, warmup, rank=0):
         dt = (time.perf_counter() - t0) / steps
     del model, dp, opt
     torch.cuda.empty_cache()
+    mm.set_gemm_backend(prev_backend)
     return {"spectra_per_s_per_gpu": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 2), "per_gpu_batch": batch,
-            "dtype": str(dtype).replace("torch.", ""), "steps": steps}
+            "dtype": str(dtype).replace("torch.", ""), "steps": steps, "gemm_backend": backend}
 
 
 def graph_leg(device, name="local_config_nocat", batch=32, steps=20):
@@ -682,6 +687,9 @@ def main():
             log("greedy recompute leg done; batch-256 and fp32 train legs")
             extras["train_batch256_bf16"] = train_leg(c, device, 256, torch.bfloat16, steps=4, warmup=2)
             extras["train_batch32_fp32"] = train_leg(c, device, 32, torch.float32, steps=5, warmup=2)
+            extras["train_own_gemms_bf16"] = train_leg(c, device, a.batch, torch.bfloat16, steps=10, warmup=3, backend="own")
+            extras["train_own_gemms_bf16"]["note"] = ("every dense product of the step on libmmhip (MM_GEMM_BACKEND=own): no "
+                                                      "hipBLASLt kernel on the path; the headline uses the per-product faster one")
             log("captured-step leg")
             extras["hip_graph_step"] = graph_leg(device)
             log("RCCL one-rank leg")
