@@ -47,6 +47,7 @@ def compute_dtype(dtype):
 # gradients, relu^2 and its derivative in GEMM epilogues): the complete hot path without the library, kept tested and timed
 # (bench.py: train_own_gemms) so that the per-product choice stays a measured one.
 _gemm_backend = os.environ.get("MM_GEMM_BACKEND", "auto")
+_DO_OWN = os.environ.get("MM_DO_OWN", "0") == "1"      # A/B: the out-projection dX product on libmmhip in the "auto" back end
 
 
 def set_gemm_backend(name: str) -> None:
@@ -596,7 +597,7 @@ class DecoderLayer(torch.autograd.Function):
         else:
             dx1, dln2w, dln2b = ops.layernorm_bwd(x1, dxf, dout, ln2w.detach(), mean2, rstd2)  # + residual gradient
             db2 = dbo = None
-        if own:
+        if own or (_DO_OWN and dt == torch.bfloat16):
             d_o = ops.gemm(dx1, cached_operand((ow,), dt, transpose=True), M, D, D).view(B, S, D)
         else:
             d_o = torch.mm(dx1, cached_operand((ow,), dt)).view(B, S, D)
