@@ -454,6 +454,127 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_pipe_k(const GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_pipe_k with the DMA spread evenly: two LDS stages for A and THREE for B (2 x 32 KB + 3 x 32 KB = 160 KB at 256 x 256).
+// A(k+1) goes out under the first half step of step k, B(k+2) under the second: one piece per 8 MFMAs of a wave all the
+// time (the pattern benchmarks/dma_issue.hip runs at 1.6 PF/s), every piece has at least half a step to land, and the wait
+// before the barrier is a counted one (the B pieces just issued stay in flight).
+// ------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void vm_wait();
+template <typename TO, int TM, int TN, int WN>
+__global__ __launch_bounds__(128 * WN, 1) void gemm_pipe3_k(const GemmP p) {
+    typedef BigTile<TM, TN, WN> G;
+    constexpr int BM = G::BM, BN = G::BN, ASZ = BM * 128, BSZ = BN * 128, CA = (BM / 8 + G::NW - 1) / G::NW, CB = BN / 8 / G::NW;
+    static_assert(WN == 4 && TN <= TM && 2 * CA - 1 <= TM && 2 * CB - 1 <= TM && CB * G::NW * 8 == BN, "piece slots per row");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* const smemB = smem + 2 * ASZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int kt0 = p.partial ? blockIdx.y * (p.k_per_split / BK) : 0;
+    const int nk = p.partial ? min(p.K / BK - kt0, p.k_per_split / BK) : p.K / BK;
+    const int nwg = p.tiles_m * p.tiles_n;
+    long m0, n0;
+    {
+        const int id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        m0 = (long)(wg / p.tiles_n) * BM; n0 = (long)(wg % p.tiles_n) * BN;
+    }
+    const int fr = lane & 15, fg = lane >> 4;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+        const int slot = ((ks * 4 + fg) ^ (fr >> 1)) << 4;
+        offA[ks] = (wr * (BM / 2) + fr) * 128 + slot;
+        offB[ks] = (wc * (BN / WN) + fr) * 128 + slot;
+    }
+    const char* const baseA = (const char*)p.A + (long)kt0 * BK * 2;
+    const char* const baseB = (const char*)p.B + (long)kt0 * BK * 2;
+    unsigned voffA[CA], voffB[CB];
+#pragma unroll
+    for (int i = 0; i < CA; i++) {
+        const int lrow = (wave + G::NW * i) * 8 + (lane >> 3);
+        long gr = m0 + lrow; if (gr > p.M - 1) gr = p.M - 1;
+        voffA[i] = (unsigned)(gr * p.lda * 2 + (((lane & 7) ^ ((lrow >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < CB; i++) {
+        const int lrow = (wave + G::NW * i) * 8 + (lane >> 3);
+        long gr = n0 + lrow; if (gr > p.N - 1) gr = p.N - 1;
+        voffB[i] = (unsigned)(gr * p.ldb * 2 + (((lane & 7) ^ ((lrow >> 1) & 7)) << 4));
+    }
+    auto uniform = [](const char* q) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)q), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)q >> 32));
+        return (const char*)(((uintptr_t)hi << 32) | lo);
+    };
+    const char *nA = baseA, *nB = baseB;                                   // scalar sources of the pieces being issued
+    unsigned char *dA = smem, *dB = smemB;                                 // their LDS stages
+    bool onA = false, onB = false;
+    auto pieceA = [&](int i) {
+        if (i < CA && onA && (wave + G::NW * i) * 8 < BM)
+            __builtin_amdgcn_global_load_lds((glb_vp)(nA + voffA[i]), (lds_vp)(dA + (wave + G::NW * i) * 1024), 16, 0, 0);
+    };
+    auto pieceB = [&](int i) {
+        if (i < CB && onB)
+            __builtin_amdgcn_global_load_lds((glb_vp)(nB + voffB[i]), (lds_vp)(dB + (wave + G::NW * i) * 1024), 16, 0, 0);
+    };
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t fa[TM], fb[2][TN];
+    // PC: 0 no pieces, 1 A pieces, 2 B pieces -- piece c goes out behind row 2c
+#define PIPE3_PHASE(SET, MMA, PF, lsA, lsB, ks, PC)                                                                      \
+    _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                     \
+        if (MMA) {                                                                                                       \
+            _Pragma("unroll") for (int j = 0; j < TN; j++)                                                               \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[SET][j], fa[i], acc[i][j], 0, 0, 0);             \
+        }                                                                                                                \
+        if (PF) {                                                                                                        \
+            fa[i] = *reinterpret_cast<const bf16x8_t*>((lsA) + offA[ks] + i * 2048);                                     \
+            if (i < TN) fb[(SET) ^ 1][i] = *reinterpret_cast<const bf16x8_t*>((lsB) + offB[ks] + i * 2048);              \
+        }                                                                                                                \
+        if ((PC) == 1 && (i & 1) == 0) pieceA(i >> 1);                                                                   \
+        if ((PC) == 2 && (i & 1) == 0) pieceB(i >> 1);                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }
+    constexpr int LAB_BASE = 2 * ASZ + 3 * BSZ;
+    auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // ---- prologue: A(0), B(0), B(1) in a burst
+    onA = onB = nk > 0; nA = uniform(baseA); nB = uniform(baseB); dA = smem; dB = smemB;
+#pragma unroll
+    for (int i = 0; i < CA; i++) pieceA(i);
+#pragma unroll
+    for (int i = 0; i < CB; i++) pieceB(i);
+    onB = nk > 1; nB = uniform(baseB + BK * 2); dB = smemB + BSZ;
+#pragma unroll
+    for (int i = 0; i < CB; i++) pieceB(i);
+    int bcur = 0;                                                          // B stage of tile kt; tile kt + 2 goes to (bcur + 2) % 3
+    for (int kt = 0; kt < nk; kt++) {
+        STAMP(kt, 0);
+        if (kt + 1 < nk) vm_wait<CB>(); else vm_wait<0>();                 // all but the B pieces issued last have landed
+        STAMP(kt, 1);
+        barrier();                                                         // A(kt), B(kt) visible; everyone has read tile kt-1
+        STAMP(kt, 2);
+        const unsigned char* lsA = smem + (kt & 1) * ASZ;
+        const unsigned char* lsB = smemB + bcur * BSZ;
+        const int b2 = bcur == 0 ? 2 : bcur - 1;                           // (bcur + 2) % 3
+        onA = kt + 1 < nk; nA = uniform(baseA + (long)(kt + 1) * BK * 2); dA = smem + ((kt + 1) & 1) * ASZ;
+        onB = kt + 2 < nk; nB = uniform(baseB + (long)(kt + 2) * BK * 2); dB = smemB + b2 * BSZ;
+        if (kt > 0) { PIPE3_PHASE(1, true, true, lsA, lsB, 0, 1) }         // second half of tile kt-1 from registers; A(kt+1) out
+        else { PIPE3_PHASE(1, false, true, lsA, lsB, 0, 1) }
+        STAMP(kt, 3);
+        PIPE3_PHASE(0, true, true, lsA, lsB, 1, 2)                         // first half of tile kt; B(kt+2) out
+        STAMP(kt, 4);
+        bcur = bcur == 2 ? 0 : bcur + 1;
+    }
+    if (nk > 0) { PIPE3_PHASE(1, true, false, smem, smemB, 0, 0) }         // second half of the last tile
+#undef PIPE3_PHASE
+    STAMP_DUMP();
+    __syncthreads();
+    big_epilogue<TO, TM, TN, G::EPI_ROW>(p, acc, smem + wave * G::EPI_WAVE, m0 + wr * (BM / 2), n0 + wc * (BN / WN), lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Ring form of gemm_big_k (same tile, waves, epilogue and contract).  Why: with two 64-deep stages the loads of step k+1 are
 // issued at the start of step k and must have landed one step later -- 70 KB in flight per CU against a loaded memory
 // latency of about 2 us: the step took the latency (1.6-2.1 us measured on every shape), not its MFMA time (1.0 us).  Here
@@ -756,7 +877,7 @@ int launch_big(const GemmP& p, hipStream_t st, int splits = 1) {
 #ifdef GEMM_LAB
     // main-loop variant of the 8-wave shapes (MM_GEMM_BIG_LOOP): two (default) | pipe | ring | reg
     static const char* loop_env = getenv("MM_GEMM_BIG_LOOP");
-    static const int loop = !loop_env ? 1 : (loop_env[0] == 'p' ? 0 : (loop_env[0] == 'r' && loop_env[1] == 'i' ? 2 : (loop_env[0] == 'r' ? 3 : 1)));
+    static const int loop = !loop_env ? 1 : (loop_env[0] == 'p' && loop_env[1] == '3' ? 4 : loop_env[0] == 'p' ? 0 : (loop_env[0] == 'r' && loop_env[1] == 'i' ? 2 : (loop_env[0] == 'r' ? 3 : 1)));
 #define LOOP_(KERNEL_, BYTES_)                                                                                                          \
     do {                                                                                                                               \
         static bool attr_ = false;                                                                                                     \
@@ -770,6 +891,7 @@ int launch_big(const GemmP& p, hipStream_t st, int splits = 1) {
     if constexpr (WN == 4) {
         const bool off32 = (size_t)p.M * p.lda * 2 < (1ull << 32) && (size_t)p.N * p.ldb * 2 < (1ull << 32);
         if (loop == 0 && off32) LOOP_(gemm_pipe_k, G::LDS_BYTES);
+        else if (loop == 4 && off32) { if constexpr (TN == 4) LOOP_(gemm_pipe3_k, (2 * G::BM * 128 + 3 * G::BN * 128)); }
         else if (loop == 2) LOOP_(gemm_ring_k, (RingTile<TM, TN, WN>::LDS_BYTES));
         else if (loop == 3 && off32) LOOP_(gemm_reg_k, G::LDS_BYTES);
         else hipLaunchKernelGGL((gemm_big_k<TO, TM, TN, WN>), grid, block, G::LDS_BYTES + LAB_LDS, st, p);
