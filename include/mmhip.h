@@ -199,6 +199,16 @@ int mm_relu2_bwd_colsum(const void* h, const void* da, void* dh, float* colsum, 
 /* out[c][r] = (out_dtype) in[r][c]: transposed compute-dtype copy of an f32 [R][C] weight (row stride ldo >= R), the
  * operand that makes dX = dY . W (autograd of nn.Linear, models/transformer_decoder.py:159-163) K-contiguous. */
 int mm_cast_transpose(const float* in, void* out, int64_t R, int64_t C, int64_t ldo, int out_dtype, void* stream);
+/* The same for many weights in ONE launch (after an optimizer step: every transposed bf16 operand copy of the decoder).
+ * descs / tile_desc live in device memory: descs[t] describes weight t (src = f32 master or its bf16 copy, [R][C]; dst = bf16
+ * [C][ldo]; tile0 = index of its first 64 x 64 tile), tile_desc[b] = t for launch block b, n_tiles = sum of ceil(R/64) *
+ * ceil(C/64).  R, C, ldo multiples of 8, bases 16-byte aligned.  Same reference lines as mm_cast_transpose. */
+typedef struct mm_transpose_desc {
+    const void* src; void* dst;
+    int64_t R, C, ldo, tile0;
+    int64_t src_dtype;                 /* MM_F32 or MM_BF16 */
+} mm_transpose_desc;
+int mm_cast_transpose_multi(const mm_transpose_desc* descs, const int32_t* tile_desc, int64_t n_tiles, void* stream);
 
 /* ---- optimizer: OrthoGrad projection + AdamW, multi-tensor (next-row N3) ---------------------
  * replaces ortho_grad.py:60-99 + torch.optim.AdamW.step.  All tables are DEVICE arrays the caller builds once:

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "mm_droppath_scale": (i32, [vp, vp, i64, f32, vp]),
     "mm_relu2_bwd_colsum": (i32, [vp, vp, vp, vp, vp, sz, i64, i64, i32, vp]),
     "mm_cast_transpose": (i32, [vp, vp, i64, i64, i64, i32, vp]),
+    "mm_cast_transpose_multi": (i32, [vp, vp, i64, vp]),
     "mm_orthograd_adamw_workspace": (sz, [i64, i64]),
     "mm_orthograd_adamw": (i32, [vp, vp, vp, vp, i64, i64, i64, f32, f32, f32, f32, f32, i64, f32, i32, i32, vp, sz, vp]),
     "mm_orthograd_adamw_dev": (i32, [vp, vp, vp, vp, i64, i64, i64, vp, f32, f32, f32, f32, f32, i32, i32, vp, sz, vp]),

@@ -410,6 +410,60 @@ extern "C" int mm_cast_transpose(const float* in, void* out, int64_t R, int64_t 
     return MM_OK;
 }
 
+// Multi-tensor form: ONE launch refreshes every transposed bf16 operand copy after an optimizer step (40 launches of 6-25 us
+// inside backward before: the small ones are latency bound).  descs[t] = one [R][C] weight (f32 master, or its bf16 operand copy
+// when the model keeps one: half the read bytes, same values) and its [C][ldo] destination; tile_desc[b] = tensor of block b.
+// Contract (checked by the caller that builds the table): C % 8 == 0, R % 8 == 0, ldo % 8 == 0, 16-byte aligned bases.
+__global__ __launch_bounds__(256) void cast_transpose_multi_k(const mm_transpose_desc* __restrict__ descs, const int* __restrict__ tile_desc) {
+    __shared__ float tile[64][65];
+    const mm_transpose_desc d = descs[tile_desc[blockIdx.x]];
+    const int R = (int)d.R, C = (int)d.C;
+    const int tcols = (C + 63) >> 6, t = blockIdx.x - (int)d.tile0;
+    const int r0 = (t / tcols) * 64, c0 = (t % tcols) * 64;
+    if (d.src_dtype == MM_BF16) {
+        const bf16* in = (const bf16*)d.src;
+        const int q = threadIdx.x & 7, rr = threadIdx.x >> 3;             // 8 chunks of 8 bf16 per tile row, 32 rows per pass
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int r = r0 + rr + 32 * i, c = c0 + q * 8;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (r < R && c < C) VecIO<bf16, 8>::load(in + (long)r * C + c, v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) tile[rr + 32 * i][q * 8 + j] = v[j];
+        }
+    } else {
+        const float* in = (const float*)d.src;
+        const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = r0 + rr + 16 * i, c = c0 + q * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < R && c < C) v = *reinterpret_cast<const float4*>(in + (long)r * C + c);
+            tile[rr + 16 * i][q * 4 + 0] = v.x; tile[rr + 16 * i][q * 4 + 1] = v.y;
+            tile[rr + 16 * i][q * 4 + 2] = v.z; tile[rr + 16 * i][q * 4 + 3] = v.w;
+        }
+    }
+    __syncthreads();
+    bf16* out = (bf16*)d.dst;
+    const int ch = threadIdx.x & 7, cc = threadIdx.x >> 3;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int c = c0 + cc + 32 * i, r = r0 + ch * 8;
+        if (c < C && r < R) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = tile[ch * 8 + j][cc + 32 * i];
+            VecIO<bf16, 8>::store(out + (long)c * d.ldo + r, v);
+        }
+    }
+}
+extern "C" int mm_cast_transpose_multi(const mm_transpose_desc* descs, const int32_t* tile_desc, int64_t n_tiles, void* stream) {
+    MM_CHECK(descs && tile_desc && n_tiles > 0, "cast_transpose_multi: bad arguments");
+    hipLaunchKernelGGL(cast_transpose_multi_k, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, descs, (const int*)tile_desc);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // DropPath factor per sample (reference models/convnext.py:13-17): out[i] = floor(keep + u[i]) / keep, u = the
 // torch.rand draw.  One launch instead of ATen's add, floor and div.

@@ -401,6 +401,67 @@ def cached_operand(params, dtype, transpose: bool = False) -> Tensor:
     return buf
 
 
+# ---- transposed operand copies, refreshed in one launch ------------------------------------------------------------------
+_tr_table = {}          # (addresses) -> device descriptor table of mm_cast_transpose_multi
+_TR_MULTI = os.environ.get("MM_TRANSPOSE_MULTI", "1") == "1"      # A/B: 0 = each copy rebuilt on first use inside backward
+
+
+def refresh_transposed_operands() -> int:
+    """Called by OrthoGradAdamW after an update: every STALE transposed bf16 operand copy whose parameters live on the current
+    device is rebuilt by ONE mm_cast_transpose_multi launch (from the bf16 operand copy when the model keeps one, else from
+    the f32 master) and re-stamped.  Returns the number of copies refreshed.  Copies it cannot take (odd sizes, other dtypes)
+    stay stale and are rebuilt on use by cached_operand, as before."""
+    if not _TR_MULTI:
+        return 0
+    import numpy as np
+    todo = []
+    for key, ent in _operand_cache.items():
+        if key[-1] is not True or key[-2] != torch.bfloat16:
+            continue
+        ps = [r() for r in ent[2]]
+        if any(p is None for p in ps) or not ps[0].is_cuda or ps[0].device != ent[1].device:
+            continue
+        stamp = tuple((p._version, p.data_ptr()) for p in ps)
+        if stamp == ent[0]:
+            continue
+        buf = ent[1]
+        ok = buf.data_ptr() % 16 == 0 and buf.stride(0) % 8 == 0 and all(
+            p.dim() == 2 and p.dtype == torch.float32 and p.is_contiguous() and p.shape[0] % 8 == 0 and p.shape[1] % 8 == 0
+            and p.data_ptr() % 16 == 0 for p in ps)
+        if ok and tuple(buf.shape) == (ps[0].shape[1], sum(p.shape[0] for p in ps)):
+            todo.append((key, ent, ps, stamp))
+    if not todo:
+        return 0
+    dev = todo[0][1][1].device
+    todo = [t for t in todo if t[1][1].device == dev]
+    rows, tiles = [], 0
+    for key, ent, ps, stamp in todo:
+        off = 0
+        for p in ps:
+            sh = shadow_of(p)
+            src = sh if (sh is not None and sh.is_contiguous() and sh.data_ptr() % 16 == 0) else p
+            R, Cc = p.shape
+            rows.append((src.data_ptr(), ent[1].data_ptr() + 2 * off, R, Cc, ent[1].stride(0), tiles,
+                         1 if src.dtype == torch.bfloat16 else 0))
+            tiles += ((R + 63) // 64) * ((Cc + 63) // 64)
+            off += R
+    tkey = tuple(r[:2] + (r[6],) for r in rows)
+    tab = _tr_table.get(dev)
+    if tab is None or tab[0] != tkey:
+        if torch.cuda.is_current_stream_capturing():
+            return 0                                   # no table yet: leave the copies to cached_operand
+        host = np.array(rows, dtype=np.int64)
+        host[:, 6] = np.where(host[:, 6] == 1, ops.L.MM_BF16, ops.L.MM_F32)
+        tile_desc = np.concatenate([np.full(((r[2] + 63) // 64) * ((r[3] + 63) // 64), i, dtype=np.int32) for i, r in enumerate(rows)])
+        tab = (tkey, torch.from_numpy(host.view(np.uint8).reshape(-1).copy()).to(dev), torch.from_numpy(tile_desc).to(dev), tiles)
+        _tr_table[dev] = tab
+    ops.L.check(ops.L.lib().mm_cast_transpose_multi(ops.L.ptr(tab[1]), ops.L.ptr(tab[2]), tab[3], ops.L.cur_stream()),
+                "mm_cast_transpose_multi")
+    for key, ent, ps, stamp in todo:
+        _operand_cache[key] = (stamp, ent[1], ent[2])
+    return len(todo)
+
+
 _shadow_index = {}
 
 

@@ -201,6 +201,7 @@ class OrthoGradAdamW(torch.optim.Optimizer):
                     self._skipped[id(p)] = self._skipped.get(id(p), 0) + 1
         self._begun = False
         self._done = set()
+        FN.refresh_transposed_operands()             # the transposed bf16 copies of what was just updated, in one launch
         return loss
 
     def _by_step(self, plist):
