@@ -83,12 +83,49 @@ _side_streams = {}
 _join_queued = False
 
 
+def _runs_beside(main: torch.cuda.Stream, cand: torch.cuda.Stream, cycles: int = 400_000) -> bool:
+    """Do kernels on `cand` run while kernels on `main` run?  HIP maps streams onto a few hardware queues (4 a process on
+    the target boxes) in creation order: two streams that land on the same queue are serialised.  Measured: after
+    torch.distributed has created RCCL's streams the first new stream shared the main stream's queue and the whole
+    parameter-gradient overlap was gone (34.3 instead of 28.4 ms per step, no two kernels ever concurrent in the trace)."""
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    with torch.cuda.stream(main):
+        torch.cuda._sleep(1000)                    # warm the spin kernel
+        e0.record()
+        torch.cuda._sleep(cycles)
+        e1.record()                                # one spin alone
+        cand.wait_event(e1)
+        with torch.cuda.stream(cand):
+            torch.cuda._sleep(cycles)
+            done = torch.cuda.Event()
+            done.record()
+        torch.cuda._sleep(cycles)
+        main.wait_event(done)
+        e2.record()                                # two spins: beside each other or one after the other
+    e2.synchronize()
+    return e1.elapsed_time(e2) < 1.5 * e0.elapsed_time(e1)
+
+
 def side_stream(device) -> torch.cuda.Stream:
     s = _side_streams.get(device)
     if s is None:
+        main = torch.cuda.current_stream(device)
         s = torch.cuda.Stream(device=device)
+        if os.environ.get("MM_SIDE_STREAM_PROBE", "1") == "1" and not torch.cuda.is_current_stream_capturing():
+            tried = [s]                            # keep the rejected ones alive so that new streams get other queues
+            for _ in range(6):
+                if _runs_beside(main, s):
+                    break
+                s = torch.cuda.Stream(device=device)
+                tried.append(s)
+            else:
+                s = tried[0]                       # none found (one hardware queue?): correctness does not depend on it
+            _rejected_streams[device] = [t for t in tried if t is not s]
         _side_streams[device] = s
     return s
+
+
+_rejected_streams = {}
 
 
 _main_of_side = {}
