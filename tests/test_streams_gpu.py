@@ -54,3 +54,23 @@ def test_two_stream_backward_completes_at_large_row_counts():
     except subprocess.TimeoutExpired:
         pytest.fail("train step with side-stream weight gradients at 20160 rows did not finish in 120 s (GEMM deadlock?)")
     assert r.returncode == 0 and "completed" in r.stdout, r.stderr[-2000:]
+
+
+def test_side_stream_runs_beside_the_main_stream_even_after_many_streams_exist():
+    """HIP maps streams onto a few hardware queues in creation order; a side stream that lands on the main stream's queue is
+    serialised with it (what happened once RCCL's streams existed: DESIGN.md 5b).  side_stream() must hand out a stream that
+    really runs beside the current one."""
+    import torch
+    from multimodal_amd import functional as FN
+    dev = torch.device("cuda", 0)
+    crowd = [torch.cuda.Stream(device=dev) for _ in range(7)]          # shift the creation order as a process group does
+    for s in crowd:
+        with torch.cuda.stream(s):
+            torch.zeros(1, device=dev)
+    saved = FN._side_streams.pop(dev, None)
+    try:
+        side = FN.side_stream(dev)
+        assert FN._runs_beside(torch.cuda.current_stream(dev), side)
+    finally:
+        if saved is not None:
+            FN._side_streams[dev] = saved
