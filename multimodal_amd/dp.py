@@ -93,6 +93,20 @@ class GradBuckets:
             torch._foreach_zero_(zero)
 
 
+_OWN_COMM_STREAM = os.environ.get("MM_DP_COMM_STREAM", "1") == "1"     # 0: async collectives on the process group's stream
+
+
+class _EventWork:
+    """Work handle of a collective issued on our own communication stream: wait() orders the current stream after it."""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+        return True
+
+
 class _Done:
     """Stand-in for a collective's work handle when the collective has already completed."""
 
@@ -173,6 +187,19 @@ class DataParallel:
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
             flat.copy_(h)
             return _Done()
+        if flat.is_cuda and _OWN_COMM_STREAM:
+            # A synchronous collective runs on the CURRENT stream (torch >= 2.8; before that on the process group's internal
+            # stream, with the current stream made to wait for it -- the event below marks completion either way).  Issued
+            # from a stream of our own choosing, RCCL's kernels get a hardware queue that neither the main nor the side
+            # stream uses (functional.comm_stream); the process group's internal stream is placed by creation order and was
+            # seen to share a queue with compute, which serialises the two.
+            cs = FN.comm_stream(flat.device)
+            cs.wait_stream(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(cs):
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
+                ev = torch.cuda.Event()
+                ev.record()
+            return _EventWork(ev)
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def _launch(self, b):

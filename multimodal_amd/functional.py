@@ -126,6 +126,28 @@ def side_stream(device) -> torch.cuda.Stream:
 
 
 _rejected_streams = {}
+_comm_streams = {}
+
+
+def comm_stream(device) -> torch.cuda.Stream:
+    """The stream gradient all-reduces are issued on (dp.DataParallel): probed like the side stream, against BOTH the main and
+    the side stream, so that with 4 hardware queues compute, parameter gradients and RCCL's kernels each get their own."""
+    s = _comm_streams.get(device)
+    if s is None:
+        main, side = main_stream(device), side_stream(device)
+        s = torch.cuda.Stream(device=device)
+        if os.environ.get("MM_SIDE_STREAM_PROBE", "1") == "1" and not torch.cuda.is_current_stream_capturing():
+            tried = [s]
+            for _ in range(8):
+                if _runs_beside(main, s) and _runs_beside(side, s):
+                    break
+                s = torch.cuda.Stream(device=device)
+                tried.append(s)
+            else:
+                s = tried[0]
+            _rejected_streams.setdefault(device, []).extend(t for t in tried if t is not s)
+        _comm_streams[device] = s
+    return s
 
 
 _main_of_side = {}
