@@ -946,14 +946,16 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_tn_k(const GemmP p) {
         const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
         m0 = (long)(wg / p.tiles_n) * BM; n0 = (long)(wg % p.tiles_n) * BN;
     }
-    // ---- staging: piece q = wave + NW*i covers bytes [1024 q, 1024 q + 1024) of the stage image [A rows | B rows]
-    const bf16* src[G::PPW];
+    // ---- staging: piece q = wave + NW*i covers bytes [1024 q, 1024 q + 1024) of the stage image [A rows | B rows]; the source is
+    // a scalar base (A or B: a piece does not straddle them) + a 32-bit lane offset (host: K * lda and K * ldb bytes below 4 GiB)
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    unsigned voff[G::PPW];
     int srow[G::PPW];
 #pragma unroll
     for (int i = 0; i < G::PPW; i++) {
-        const int q = wave + G::NW * i;
+        const int q = swave + G::NW * i;
         int off = q * 1024 + lane * 16;
-        const bool isA = off < A_BYTES;
+        const bool isA = q * 1024 < A_BYTES;                                  // wave-uniform (A_BYTES % 1024 == 0)
         if (!isA) off -= A_BYTES;
         const int pitch = isA ? PA : PB;
         const int row = off / pitch, c16 = (off % pitch) >> 4;
@@ -962,19 +964,38 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_tn_k(const GemmP p) {
         long col = (isA ? m0 : n0) + lc16 * 8;
         const long lim = (isA ? p.M : p.N) - 8;
         if (col > lim) col = lim;
-        src[i] = (isA ? (const bf16*)p.A + col : (const bf16*)p.B + col) + (long)(kt0 * BK + row) * (isA ? p.lda : p.ldb);
+        voff[i] = (unsigned)(((long)(kt0 * BK + row) * (isA ? p.lda : p.ldb) + col) * 2);
         srow[i] = kt0 * BK + row;
     }
-    auto stage = [&](int kt, int buf) {
+    auto uniform = [](const char* q) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)q), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)q >> 32));
+        return (const char*)(((uintptr_t)hi << 32) | lo);
+    };
+    // fetched once: behind a memory clobber the compiler re-loads the symbol's address (s_load + lgkmcnt(0): ~170 cycles) per piece
+    const char* const zero_page = uniform(reinterpret_cast<const char*>(g_zero_page));
+    auto stage = [&](int kt, int buf, int part = 0) {                        // part 0: all pieces, 1 / 2: first / second half
         unsigned char* base = smem + buf * G::STAGE_BYTES;
+        const char* sA = uniform((const char*)p.A + (long)kt * BK * p.lda * 2);
+        const char* sB = uniform((const char*)p.B + (long)kt * BK * p.ldb * 2);
+        const bool tail = (kt0 + kt + 1) * BK > p.K;                          // scalar: only the last K step of a problem
 #pragma unroll
         for (int i = 0; i < G::PPW; i++) {
-            const int q = wave + G::NW * i;
+            const int q = swave + G::NW * i;
+            if (part == 1 && i >= G::PPW / 2) continue;
+            if (part == 2 && i < G::PPW / 2) continue;
             if (q < G::PIECES) {                                             // wave-uniform
-                const bool isA = q * 1024 < A_BYTES;                          // pieces do not straddle A | B (A_BYTES % 1024 == 0)
-                const bf16* s = src[i] + (long)kt * BK * (isA ? p.lda : p.ldb);
-                if (srow[i] + kt * BK >= p.K) s = reinterpret_cast<const bf16*>(g_zero_page);
-                __builtin_amdgcn_global_load_lds((glb_vp)s, (lds_vp)(base + q * 1024), 16, 0, 0);
+                const unsigned lds_addr = (unsigned)(uintptr_t)(lds_vp)(base + q * 1024);
+                if (!tail) {                     // every k-row of this stage exists: scalar base + lane offset, no vector ALU work
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff[i]),
+                                 "s"(q * 1024 < A_BYTES ? sA : sB) : "memory", "m0");
+                    continue;
+                }
+                const char* s = (q * 1024 < A_BYTES ? sA : sB) + voff[i];
+                if (srow[i] + kt * BK >= p.K) s = zero_page;
+                // Issued through inline asm on purpose: behind the builtin the compiler orders every later ds_read_b64_tr_b16
+                // (an intrinsic it cannot disambiguate from the DMA's LDS write) after the DMA with s_waitcnt vmcnt(0), i.e.
+                // each K step waited for the loads it had just issued.  Ordering is ours anyway: vmcnt(0) + barrier per step.
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(s) : "memory", "m0");
             }
         }
     };
@@ -992,35 +1013,69 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_tn_k(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     typedef bf16x4_t __attribute__((address_space(3))) * lds4p;
-    for (int kt = 0; kt < nk; kt++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const unsigned char* ls = smem + (kt & 1) * G::STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            bf16x8_t fa[TM], fb[TN];
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const unsigned char* a0 = ls + rowoff_b + ks * 32 * PB + (((cbase_b + j) ^ swB) << 5);
-                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(a0));
-                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(a0 + 4 * PB));
-                fb[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                const unsigned char* a0 = ls + rowoff_a + ks * 32 * PA + (((cbase_a + i) ^ swA) << 5);
-                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(a0));
-                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(a0 + 4 * PA));
-                fa[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
+    constexpr int LAB_BASE = G::LDS_BYTES;
+    bf16x8_t fa[TM], fb[TN];
+#define TN_RD(ls, ks)                                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < TN; j++) {                                                                   \
+        const unsigned char* a0 = (ls) + rowoff_b + (ks) * 32 * PB + (((cbase_b + j) ^ swB) << 5);                     \
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(a0));                                      \
+        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(a0 + 4 * PB));                             \
+        fb[j] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                                      \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                   \
+        const unsigned char* a0 = (ls) + rowoff_a + (ks) * 32 * PA + (((cbase_a + i) ^ swA) << 5);                     \
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(a0));                                      \
+        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4p)(a0 + 4 * PA));                             \
+        fa[i] = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                                      \
     }
+#define TN_MM()                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < TM; i++)                                                                     \
+        _Pragma("unroll") for (int j = 0; j < TN; j++)                                                                 \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    // the two waves of a SIMD run half a K step apart; the late one issues its DMA pieces after its held MFMAs (gemm_big_k)
+    const bool late = p.stagger && __builtin_amdgcn_readfirstlane(wave) >= G::NW / 2;
+    if (!late) {
+        for (int kt = 0; kt < nk; kt++) {
+            STAMP(kt, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(kt, 1);
+            __syncthreads();
+            STAMP(kt, 2);
+            const bool halves = p.stagger == 2;
+            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1, halves ? 1 : 0);
+            STAMP(kt, 3);
+            const unsigned char* ls = smem + (kt & 1) * G::STAGE_BYTES;
+            TN_RD(ls, 0) TN_MM()
+            if (halves && kt + 1 < nk) stage(kt + 1, (kt + 1) & 1, 2);
+            STAMP(kt, 4);
+            TN_RD(ls, 1) TN_MM()
+            STAMP(kt, 5);
+        }
+    } else {
+        for (int kt = 0; kt < nk; kt++) {
+            STAMP(kt, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(kt, 1);
+            __syncthreads();
+            STAMP(kt, 2);
+            const unsigned char* ls = smem + (kt & 1) * G::STAGE_BYTES;
+            if (kt > 0) { TN_MM() }
+            STAMP(kt, 3);
+            const bool halves = p.stagger == 2;
+            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1, halves ? 1 : 0);
+            STAMP(kt, 4);
+            TN_RD(ls, 0) TN_MM()
+            if (halves && kt + 1 < nk) stage(kt + 1, (kt + 1) & 1, 2);
+            STAMP(kt, 5);
+            TN_RD(ls, 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            STAMP(kt, 6);
+        }
+        if (nk > 0) { TN_MM() }
+    }
+#undef TN_RD
+#undef TN_MM
+    STAMP_DUMP();
     __syncthreads();
     big_epilogue<TO, TM, TN, G::EPI_ROW>(p, acc, smem + G::STAGE_BYTES + wave * G::EPI_WAVE, m0 + wr * (BM / 2), n0 + wc * (BN / WN), lane);
 }
@@ -1030,12 +1085,12 @@ int launch_big_tn(const GemmP& p, hipStream_t st, int splits) {
     typedef BigTile<TM, TN, 4> G;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_big_tn_k<TO, TM, TN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_big_tn_k<TO, TM, TN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + LAB_LDS);
         if (e != hipSuccess) MM_FAIL(MM_ERR_LAUNCH, "gemm_big_tn: cannot raise dynamic LDS to %d bytes: %s", G::LDS_BYTES, hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((gemm_big_tn_k<TO, TM, TN, 4>), dim3((unsigned)tiles, (unsigned)splits), dim3(512), G::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_big_tn_k<TO, TM, TN, 4>), dim3((unsigned)tiles, (unsigned)splits), dim3(512), G::LDS_BYTES + LAB_LDS, st, p);
     MM_LAUNCH_CHECK();
     if (p.partial) {
         const long nq = (long)p.M * ((p.N + 3) / 4);
@@ -1149,6 +1204,7 @@ bool gemm_big_tn_applicable(const GemmP& p, int dtype, int a_kmajor, int b_kmajo
     static const bool off = getenv("MM_GEMM_NO_TN") != nullptr;              // A/B switch
     if (off || dtype != MM_BF16 || !a_kmajor || !b_kmajor || splits > 1 || p.partial) return false;
     if (!p.a_vec || !p.b_vec || p.M % 8 || p.N % 8 || p.M < 256 || p.N < 256 || p.K < 1024) return false;
+    if ((size_t)p.K * p.lda * 2 >= (1ull << 32) || (size_t)p.K * p.ldb * 2 >= (1ull << 32)) return false;    // 32-bit lane offsets
     return (long)p.M * p.N >= 256L * 256 * 12;
 }
 
@@ -1156,6 +1212,10 @@ int gemm_big_tn_launch(GemmP& p, int out_dtype, hipStream_t st, void* ws, size_t
     const int osz = out_dtype == MM_BF16 ? 2 : 4;
     auto al = [&](const void* q) { return q == nullptr || ((uintptr_t)q) % 16 == 0; };
     p.o_vec = (p.ldo * osz) % 16 == 0 && al(p.out) && al(p.pre) && al(p.mul) && al(p.res);
+    // staggered waves (as in gemm_big_k) measured faster on the 256 x 256 tile alone and slower over the shapes the cost model
+    // picks (registers: the 320-wide tiles): off unless asked for
+    static const char* fstag = getenv("MM_GEMM_TN_STAGGER");               // "0" / "1" / "2": benchmark override
+    p.stagger = fstag ? atoi(fstag) : 0;
     struct Cand { int tm, tn; };
     static const Cand cands[3] = {{8, 4}, {8, 5}, {10, 4}};                   // 256x256, 256x320, 320x256
     const long ksteps = cdiv(p.K, BK);

@@ -550,6 +550,7 @@ def shadows_written(params) -> None:
 
 
 _DW_SMALL_OWN = os.environ.get("MM_DW_SMALL_OWN", "0") == "1"
+_DW_OWN = os.environ.get("MM_DW_OWN", "0")
 
 
 def _mm_f32(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
@@ -560,6 +561,11 @@ def _mm_f32(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
     # step its 250 512-thread workgroups crowd the main stream's kernels (25.70 vs 25.49 ms per step, three A/B pairs): off.
     small = _DW_SMALL_OWN and a.dtype == torch.bfloat16 and a.shape[0] * b.shape[1] <= (1 << 22) and b.shape[0] >= 4096 and \
         a.shape[0] >= 256 and b.shape[1] >= 256 and a.shape[0] % 8 == 0 and b.shape[1] % 8 == 0
+    # MM_DW_OWN (A/B): "ffn" = the two d_model x d_ffn weight gradients on the libmmhip tile (240 / 218 us alone against the
+    # library's 265 / 231 since the DMA of that kernel goes out through inline asm), "all" = every large one
+    if _DW_OWN != "0" and a.dtype == torch.bfloat16 and b.shape[0] >= 4096 and a.shape[0] % 8 == 0 and b.shape[1] % 8 == 0:
+        big = a.shape[0] * b.shape[1] >= (1 << 23)
+        small = small or _DW_OWN == "all" or (_DW_OWN == "ffn" and big) or (_DW_OWN == "ffn+o" and (big or a.shape[0] == b.shape[1]))
     if _gemm_backend == "own" or small:
         dy2 = a.t()                               # [rows, n] with unit inner stride again
         n, k, rows = dy2.shape[1], b.shape[1], b.shape[0]
