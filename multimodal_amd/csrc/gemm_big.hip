@@ -275,6 +275,9 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_k(const GemmP p) {
             for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const bf16x8_t*>(ls + offB[ks] + j * 2048);
 #pragma unroll
             for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const bf16x8_t*>(ls + offA[ks] + i * 2048);
+            // all fragment reads of the half step are issued before its first MFMA (left alone the compiler alternates two
+            // reads, a full lgkmcnt(0) wait and ten MFMAs, exposing the LDS latency five times a half step): 4-5 %
+            __builtin_amdgcn_sched_barrier(0);
         };
         auto mm = [&]() {
 #pragma unroll
@@ -950,7 +953,12 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_tn_k(const GemmP p) {
     // a scalar base (A or B: a piece does not straddle them) + a 32-bit lane offset (host: K * lda and K * ldb bytes below 4 GiB)
     const int swave = __builtin_amdgcn_readfirstlane(wave);
     unsigned voff[G::PPW];
-    int srow[G::PPW];
+    auto piece_row = [&](int q) {                                             // k-row (inside a stage) of this lane's 16 bytes of piece q
+        int off = q * 1024 + lane * 16;
+        const bool isA = q * 1024 < A_BYTES;
+        if (!isA) off -= A_BYTES;
+        return off / (isA ? PA : PB);
+    };
 #pragma unroll
     for (int i = 0; i < G::PPW; i++) {
         const int q = swave + G::NW * i;
@@ -965,7 +973,6 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_tn_k(const GemmP p) {
         const long lim = (isA ? p.M : p.N) - 8;
         if (col > lim) col = lim;
         voff[i] = (unsigned)(((long)(kt0 * BK + row) * (isA ? p.lda : p.ldb) + col) * 2);
-        srow[i] = kt0 * BK + row;
     }
     auto uniform = [](const char* q) {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)q), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)q >> 32));
@@ -991,7 +998,7 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_tn_k(const GemmP p) {
                     continue;
                 }
                 const char* s = (q * 1024 < A_BYTES ? sA : sB) + voff[i];
-                if (srow[i] + kt * BK >= p.K) s = zero_page;
+                if ((kt0 + kt) * BK + piece_row(q) >= p.K) s = zero_page;
                 // Issued through inline asm on purpose: behind the builtin the compiler orders every later ds_read_b64_tr_b16
                 // (an intrinsic it cannot disambiguate from the DMA's LDS write) after the DMA with s_waitcnt vmcnt(0), i.e.
                 // each K step waited for the loads it had just issued.  Ordering is ours anyway: vmcnt(0) + barrier per step.
@@ -1033,7 +1040,11 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_tn_k(const GemmP p) {
         _Pragma("unroll") for (int j = 0; j < TN; j++)                                                                 \
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     // the two waves of a SIMD run half a K step apart; the late one issues its DMA pieces after its held MFMAs (gemm_big_k)
+#ifdef GEMM_LAB
     const bool late = p.stagger && __builtin_amdgcn_readfirstlane(wave) >= G::NW / 2;
+#else
+    constexpr bool late = false;                 // staggered waves: faster on the 256 x 256 tile alone, slower on the 320-wide ones (registers)
+#endif
     if (!late) {
         for (int kt = 0; kt < nk; kt++) {
             STAMP(kt, 0);
