@@ -223,7 +223,10 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_k(const GemmP p) {
     }
 
     // ---- staging: piece q = wave + NW*i covers rows 8q .. 8q+7 of the stacked [A rows ; B rows] image
-    const bf16* src[G::PPW];
+    // The source of a piece is a scalar base (A or B: a piece never straddles them; advanced by the K step) + a 32-bit lane
+    // offset (host: M * lda and N * ldb bytes below 4 GiB), and the piece goes out through inline asm in that form: no vector
+    // ALU work and no branch per piece (the builtin took a 64-bit lane address: an add and a select pair per piece).
+    unsigned voff[G::PPW];
     auto tile_origin = [&](int id, long& m0, long& n0) {              // XCD-aware bijective remap, N fastest
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
         const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
@@ -233,23 +236,29 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_k(const GemmP p) {
 #pragma unroll
         for (int i = 0; i < G::PPW; i++) {
             const int q = wave + G::NW * i;
-            const int row = q * 8 + (lane >> 3);                       // stacked row; the swizzle uses the operand-local row
-            const bool isA = row < BM;
-            const int lrow = isA ? row : row - BM;
+            const bool isA = q * 8 < BM;                               // wave-uniform (BM % 8 == 0)
+            const int lrow = q * 8 + (lane >> 3) - (isA ? 0 : BM);     // operand-local row (the swizzle uses it)
             const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);
             long gr = (isA ? m0 : n0) + lrow;
             const long lim = (isA ? p.M : p.N) - 1;
             if (gr > lim) gr = lim;
-            src[i] = (isA ? (const bf16*)p.A + gr * p.lda : (const bf16*)p.B + gr * p.ldb) + chunk * 8;
+            voff[i] = (unsigned)(gr * (isA ? p.lda : p.ldb) * 2 + chunk * 16);
         }
     };
+    auto uniform = [](const char* q) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)q), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)q >> 32));
+        return (const char*)(((uintptr_t)hi << 32) | lo);
+    };
     auto stage = [&](int kt, int buf) {
-        unsigned char* base = smem + buf * G::STAGE_BYTES;
+        const unsigned lds0 = (unsigned)(uintptr_t)(lds_vp)(smem + buf * G::STAGE_BYTES);
+        const char* sA = uniform((const char*)p.A + (long)(kt0 + kt) * BK * 2);
+        const char* sB = uniform((const char*)p.B + (long)(kt0 + kt) * BK * 2);
 #pragma unroll
         for (int i = 0; i < G::PPW; i++) {
             const int q = wave + G::NW * i;
             if (q < G::PIECES)                                         // wave-uniform
-                __builtin_amdgcn_global_load_lds((glb_vp)(src[i] + (long)(kt0 + kt) * BK), (lds_vp)(base + q * 1024), 16, 0, 0);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds0 + q * 1024), "v"(voff[i]),
+                             "s"(q * 8 < BM ? sA : sB) : "memory", "m0");
         }
     };
     // ---- one output tile per workgroup (a persistent variant with next-tile prefetch measured no faster and cost
@@ -1146,6 +1155,7 @@ double shape_cost(const GemmP& p, Shape s, bool allow_split = false) {
 bool gemm_big_applicable(const GemmP& p, int dtype, int a_kmajor, int b_kmajor, int splits) {
     if (dtype != MM_BF16 || a_kmajor || b_kmajor || splits > 1 || p.partial) return false;
     if (!p.a_vec || !p.b_vec || p.K % BK != 0) return false;
+    if ((size_t)p.M * p.lda * 2 >= (1ull << 32) || (size_t)p.N * p.ldb * 2 >= (1ull << 32)) return false;      // 32-bit lane offsets
     // 256x256-class tiles from a quarter of the chip up; the 4-wave shapes for skinny problems from about 1000 x 1000 x 1000
     // (measured: below that gemm_k's 64x64 tiles are as fast -- 13 us at 1984 x 1024 x 256 either way -- and the
     // one-K-step products of the first encoder stages are slower here)
