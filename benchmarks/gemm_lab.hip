@@ -58,10 +58,10 @@ int main(int argc, char** argv) {
     for (int w = 0; w < 8; w++) {
         printf("wave %d:", w);
         double per = 0; int np = 0;
-        for (int k = 1; k < 16; k++) if (st[w][k][0] && st[w][k - 1][0]) { per += (double)(st[w][k][0] - st[w][k - 1][0]); np++; }
+        for (int k = 1; k < 16; k++) if (st[w][k][0] > st[w][k - 1][0] && st[w][k - 1][0] && st[w][k][0] - st[w][k - 1][0] < 10000000ull) { per += (double)(st[w][k][0] - st[w][k - 1][0]); np++; }
         for (int s = 0; s < 7; s++) {
             double d = 0; int n = 0;
-            for (int k = 0; k < 16; k++) if (st[w][k][s + 1] && st[w][k][s]) { d += (double)(st[w][k][s + 1] - st[w][k][s]); n++; }
+            for (int k = 0; k < 16; k++) if (st[w][k][s + 1] > st[w][k][s] && st[w][k][s] && st[w][k][s + 1] - st[w][k][s] < 10000000ull) { d += (double)(st[w][k][s + 1] - st[w][k][s]); n++; }
             if (n) printf("  s%d->s%d %6.0f", s, s + 1, d / n);
         }
         printf("  | period %6.0f cycles\n", np ? per / np : 0.0);
