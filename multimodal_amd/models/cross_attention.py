@@ -1,7 +1,7 @@
 """CrossAttentionBlock: API-compatible with reference models/cross_attention.py:6-46 (dead code there: it imports a
 missing `.rope`).  Built on the same fused attention kernel (K3) with an empty causal part: every query row is a
 "prompt" row of a [kv ; q] sequence is NOT needed -- cross attention is plain full attention of Tq queries over Tkv
-keys, which K3 computes when q and kv have equal length; for the general case the keys/values are padded views.
+keys, which K3 computes when q and kv have equal length; shorter query sets are padded, longer ones go through in chunks.
 PARITY UNPINNED: the reference class cannot be imported, no reference output exists (oracle restates the text)."""
 import torch
 import torch.nn as nn
@@ -35,17 +35,19 @@ class CrossAttentionBlock(nn.Module):
         q = F.linear(query.to(dt), self.linear_q.weight.to(dt), self.linear_q.bias.to(dt))
         k = F.linear(key_value.to(dt), self.linear_k.weight.to(dt), self.linear_k.bias.to(dt))
         v = F.linear(key_value.to(dt), self.linear_v.weight.to(dt), self.linear_v.bias.to(dt))
-        # one [kv ; q] sequence with prompt_len = Tkv would let queries see themselves; instead run K3 on a sequence of
-        # S = max(Tq, Tkv) rows where every row is a prompt row (full attention), with zero-padded tails masked out by
-        # construction: padded KEY rows must not be seen, so keys are only padded when Tq > Tkv is not the case.
-        if Tq > Tkv:
-            raise NotImplementedError("CrossAttentionBlock on libmmhip needs Tq <= Tkv (queries are padded, keys are not)")
+        # K3 computes full attention of S rows over S keys when every row is a prompt row (prompt_len = S).  Keys must not be
+        # padded (a padded key row would be seen), queries may: the queries go through in chunks of at most Tkv rows, each
+        # padded to Tkv (the padded query rows are computed and dropped).
         S = Tkv
-        qkv = torch.zeros((B, S, 3, C), dtype=dt, device=q.device)
-        qkv[:, :Tq, 0] = q
-        qkv[:, :, 1] = k
-        qkv[:, :, 2] = v
         zero = torch.zeros((S, 0), dtype=torch.float32, device=q.device)
-        a = FN.PrefixAttention.apply(qkv, zero, zero, self.num_heads, 0, S, False)[:, :Tq]
+        parts = []
+        for t0 in range(0, Tq, S):
+            n = min(S, Tq - t0)
+            qkv = torch.zeros((B, S, 3, C), dtype=dt, device=q.device)
+            qkv[:, :n, 0] = q[:, t0: t0 + n]
+            qkv[:, :, 1] = k
+            qkv[:, :, 2] = v
+            parts.append(FN.PrefixAttention.apply(qkv, zero, zero, self.num_heads, 0, S, False)[:, :n])
+        a = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
         out = query.to(dt) + F.linear(a, self.out_proj.weight.to(dt), self.out_proj.bias.to(dt))
         return FN.LayerNorm.apply(out, self.norm.weight, self.norm.bias)

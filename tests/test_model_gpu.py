@@ -265,6 +265,11 @@ def test_cross_attention_block_vs_text_restatement():
     ref = restate.cross_attention_block(sd, "x.", q, kv, 4)
     y = blk.to(DEV).eval()(q.to(DEV), kv.to(DEV))
     assert rel_err(y.cpu(), ref) < 1e-4
+    # more queries than keys (the reference class accepts any Tq / Tkv): query chunks of at most Tkv rows
+    q2 = fill.synth_ir(2, 70 * 128, 5).view(2, 70, 128) - 0.5
+    ref2 = restate.cross_attention_block(sd, "x.", q2, kv, 4)
+    y2 = blk(q2.to(DEV), kv.to(DEV))
+    assert y2.shape == q2.shape and rel_err(y2.cpu(), ref2) < 1e-4
 
 
 # ---- the "own" GEMM backend: every dense product of the decoder on libmmhip (no library GEMM anywhere on the path)
