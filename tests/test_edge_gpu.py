@@ -1,7 +1,7 @@
 """Edge cases of the hot path on the GPU (product modules, HIP through the C ABI) against tests/golden/edge.npz, which the
 reference itself produced (oracle/gen_golden_edge.py): nmr_tokens=None, both truncation rules, B=1/T=1, a memory_proj
 Linear (memory_dim != embed_dim), the length guard's ValueError, and [PAD]-ragged targets through CE(ignore_index=0).
-Tolerances as in test_model_gpu.py: fp32 1e-4 on logits, 1e-3 on gradients; bf16 5e-2 on logits."""
+Tolerances as in test_model_gpu.py: fp32 1e-4 on logits, 1e-3 on gradients; bf16 2e-2 on logits."""
 import os
 
 import numpy as np
