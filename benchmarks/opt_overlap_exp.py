@@ -89,7 +89,7 @@ def timeit(fn, n=20, w=5):
 
 
 print(f"plain: {timeit(step_plain):.2f} ms/step", flush=True)
-model.decoder.register_forward_pre_hook(launch_deferred)
+(model if os.environ.get('HOOK') == 'model' else model.decoder).register_forward_pre_hook(launch_deferred)   # HOOK=model: beside the encoder forward too
 for i, l in enumerate(layers):
     if i >= FIRST:
         l.register_forward_pre_hook(make_wait(i))

@@ -180,6 +180,81 @@ class OrthoGradAdamW(torch.optim.Optimizer):
                 self._run(("subset", tag, gi, j), self.param_groups[gi], sub, stp)
             self._done.update(id(p) for p in plist)
 
+    # ---- deferral into the next forward: the updates of the decoder layers (95 % of the parameters: 2 ms of HBM-bound work)
+    # run on the side stream at the top of the NEXT forward, beside the encoder's ~150 small latency-bound kernels, each layer's
+    # forward waiting only for its own update.  Same kernels, same inputs, same order per tensor: the parameters after step k
+    # are bit-identical to the plain optimizer's; they just become so when the next forward (or flush_deferred) asks for them.
+    _HYPER = ("lr", "betas", "eps", "weight_decay", "ortho", "ortho_eps", "rescale")
+
+    def defer_into_next_forward(self, model, layer_modules):
+        """Call once after construction.  `layer_modules`: the modules whose parameters may be updated late, in forward order
+        (model.decoder.layers).  Everything else is updated inside step() as before.  Hooks on `model` launch / await the
+        updates; state_dict() of the model or of this optimizer, zero_grad() of this optimizer and flush_deferred() complete
+        them first.  Gradients must not be zeroed IN PLACE between step() and the next forward (DataParallel.zero_grad and
+        zero_grad(set_to_none=True) only drop the references, which step() keeps)."""
+        self._defer_layers = [[p for p in m.parameters()] for m in layer_modules]
+        self._defer_ids = set(id(p) for ps in self._defer_layers for p in ps)
+        self._pending = None
+        self._defer_events = {}
+        model.register_forward_pre_hook(lambda m, a: self.flush_deferred())
+        for i, m in enumerate(layer_modules):
+            m.register_forward_pre_hook(lambda mod, a, i=i: self._await_deferred(i))
+        model.register_forward_hook(lambda m, a, o: self._await_deferred(None))
+        model.register_state_dict_pre_hook(lambda *a, **k: self.flush_deferred(wait=True))
+
+    def _await_deferred(self, i):
+        evs = getattr(self, "_defer_events", None)
+        if not evs:
+            return
+        keys = [i] if i is not None else list(evs.keys())
+        for k in keys:
+            ev = evs.pop(k, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
+    @torch.no_grad()
+    def flush_deferred(self, wait=False):
+        """Launch the pending deferred updates now (side stream; events per layer).  wait=True: the current stream also waits
+        for all of them (before reading parameters outside a forward: checkpoints, evaluation through other entry points)."""
+        pend = getattr(self, "_pending", None)
+        if pend:
+            self._pending = None
+            dev = next(p for items in pend for p, _ in items).device
+            if not dev.type == "cuda":
+                raise RuntimeError("OrthoGradAdamW: deferred updates need GPU parameters")
+            main, side = FN.enter_side(dev)            # after everything the main stream was given: gradients are final
+            now = [{k: g[k] for k in self._HYPER} for g in self.param_groups]
+            for g, h in zip(self.param_groups, self._pending_hyper):      # the hyper-parameters step() was called with
+                g.update(h)
+            with torch.cuda.stream(side):
+                for i, items in enumerate(pend):
+                    if not items:
+                        continue
+                    ps = [p for p, _ in items]
+                    kept = [p.grad for p in ps]
+                    for p, g in items:
+                        p.grad = g
+                    self.step_subset(ps, ("deferred", i))
+                    for p, g in zip(ps, kept):
+                        p.grad = g
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    self._defer_events[i] = ev
+                FN.refresh_transposed_operands()
+                ev = torch.cuda.Event()
+                ev.record(side)
+                self._defer_events["transposed"] = ev
+            for g, h in zip(self.param_groups, now):
+                g.update(h)
+            self._begun = False
+            self._done = set()
+        if wait:
+            self._await_deferred(None)
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.flush_deferred(wait=True)                  # an in-place zero must not reach gradients still to be applied
+        super().zero_grad(set_to_none=set_to_none)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -188,6 +263,26 @@ class OrthoGradAdamW(torch.optim.Optimizer):
                 loss = closure()
         begun = getattr(self, "_begun", False)
         capturing = self.capturable and torch.cuda.is_current_stream_capturing()
+        if getattr(self, "_defer_ids", None) and not begun and not capturing and not self.capturable:
+            self.flush_deferred()                       # a step without a forward in between: apply the older update first
+            FN.join_side_stream()
+            self.begin_step()
+            early, late_missing = [], []
+            for group in self.param_groups:
+                for p in group["params"]:
+                    if p.grad is None:
+                        self._skipped[id(p)] = self._skipped.get(id(p), 0) + 1
+                    elif id(p) not in self._defer_ids:
+                        early.append(p)
+            self.step_subset(early, "early")
+            self._pending = [[(p, p.grad) for p in ps if p.grad is not None] for ps in self._defer_layers]
+            self._pending_hyper = [{k: g[k] for k in self._HYPER} for g in self.param_groups]   # a scheduler may move lr before the flush
+            if not any(self._pending):
+                self._pending = None
+                self._begun = False
+                self._done = set()
+            FN.refresh_transposed_operands()
+            return loss
         if not begun and not capturing:          # under capture the replaying caller advances (graph.CapturedTrainStep)
             self.advance()
         done = self._done if begun else ()
@@ -216,6 +311,7 @@ class OrthoGradAdamW(torch.optim.Optimizer):
     # ---- checkpoint layout of the reference (ortho_grad.py:111-129: the wrapper's own state is empty, the wrapped AdamW's
     # state_dict sits under 'base_optimizer' with torch's per-parameter {'step', 'exp_avg', 'exp_avg_sq'})
     def state_dict(self):
+        self.flush_deferred(wait=True)
         sd = super().state_dict()
         order = [p for g in self.param_groups for p in g["params"]]
         state = {}

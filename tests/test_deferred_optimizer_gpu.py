@@ -1,0 +1,83 @@
+"""OrthoGradAdamW.defer_into_next_forward: the decoder layers' updates run at the top of the next forward on the side stream.
+Same kernels on the same inputs: parameters, moments and losses must be BIT-identical to the plain optimizer's (reference
+semantics: ortho_grad.py:60-99 + torch.optim.AdamW.step, train_autoregressive.py:698-704)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _model():
+    from multimodal_amd.models import MultiModalToSMILESModel
+    torch.manual_seed(3)
+    return MultiModalToSMILESModel(64, 50, max_seq_length=24, max_nmr_length=16, max_memory_length=32, embed_dim=128, num_heads=4,
+                                   num_layers=3, dropout=0.0, verbose=False, use_stablemax=True).to(DEV).train()
+
+
+def _run(defer, use_dp, dtype, steps=4):
+    import multimodal_amd as mm
+    from multimodal_amd.dp import DataParallel
+    from multimodal_amd.optim import OrthoGradAdamW
+    with mm.compute_dtype(dtype):
+        m = _model()
+        dp = DataParallel(m) if use_dp else None
+        opt = OrthoGradAdamW(m.parameters(), lr=1e-2, eps=1e-8, ortho_eps=1e-8, weight_decay=0.01)
+        if defer:
+            opt.defer_into_next_forward(m, m.decoder.layers)
+        g = torch.Generator().manual_seed(5)
+        losses = []
+        for s in range(steps):
+            ir = torch.rand(4, 1000, generator=g).to(DEV)
+            nmr = torch.randint(0, 50, (4, 16), generator=g).to(DEV)
+            tgt = torch.randint(5, 64, (4, 24), generator=g).to(DEV)
+            for grp in opt.param_groups:                                  # a schedule: the deferred update must use the lr of ITS step
+                grp["lr"] = 1e-2 * (s + 1) / steps
+            dp.zero_grad() if use_dp else opt.zero_grad(set_to_none=True)
+            lg = m(nmr, ir, tgt[:, :-1], None)
+            loss = torch.nn.functional.cross_entropy(lg.reshape(-1, 64), tgt[:, 1:].reshape(-1))
+            loss.backward()
+            if use_dp:
+                dp.finish()
+            opt.step()
+            losses.append(loss.item())
+        sd = {k: v.clone() for k, v in m.state_dict().items()}              # the state_dict pre-hook completes the updates
+        osd = copy.deepcopy(opt.state_dict())
+    return losses, sd, osd
+
+
+@pytest.mark.parametrize("use_dp", [True, False])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_deferred_updates_are_bit_identical(use_dp, dtype):
+    l0, sd0, o0 = _run(False, use_dp, dtype)
+    l1, sd1, o1 = _run(True, use_dp, dtype)
+    assert l0 == l1
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+    s0, s1 = o0["base_optimizer"]["state"], o1["base_optimizer"]["state"]
+    assert s0.keys() == s1.keys()
+    for i in s0:
+        for kk in ("exp_avg", "exp_avg_sq", "step"):
+            assert torch.equal(s0[i][kk], s1[i][kk]), (i, kk)
+
+
+def test_in_place_zero_grad_flushes_first():
+    import multimodal_amd as mm
+    from multimodal_amd.optim import OrthoGradAdamW
+    with mm.compute_dtype(torch.float32):
+        m = _model()
+        opt = OrthoGradAdamW(m.parameters(), lr=1e-2)
+        opt.defer_into_next_forward(m, m.decoder.layers)
+        w = m.decoder.layers[1].ffn_w1.weight if hasattr(m.decoder.layers[1], "ffn_w1") else next(m.decoder.layers[1].parameters())
+        before = w.detach().clone()
+        g = torch.Generator().manual_seed(1)
+        ir = torch.rand(2, 1000, generator=g).to(DEV); nmr = torch.randint(0, 50, (2, 16), generator=g).to(DEV)
+        tgt = torch.randint(5, 64, (2, 24), generator=g).to(DEV)
+        torch.nn.functional.cross_entropy(m(nmr, ir, tgt[:, :-1], None).reshape(-1, 64), tgt[:, 1:].reshape(-1)).backward()
+        opt.step()
+        assert opt._pending is not None and torch.equal(w.detach(), before)       # not applied yet
+        opt.zero_grad(set_to_none=False)                                           # the reference's OrthoGrad.zero_grad default
+        torch.cuda.synchronize()
+        assert opt._pending is None and not torch.equal(w.detach(), before)        # applied before the gradients were zeroed
