@@ -9,9 +9,14 @@ rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0"), r.get("Stream_Id", "0")))
 rows.sort()
-# steps are delimited by the optimizer's og_adamw_k launches
-ends = [i for i, r in enumerate(rows) if r[2].startswith("og_adamw_k")]
+# steps are delimited by the optimizer's og_adamw_k launch at the END of a step: with the decoder updates deferred into the next
+# forward there are more launches per step (the deferred ones follow within a few ms), so only a launch whose predecessor is
+# more than 8 ms older counts
+adam = [i for i, r in enumerate(rows) if r[2].startswith("og_adamw_k")]
+ends = [i for n, i in enumerate(adam) if n == 0 or rows[i][0] - rows[adam[n - 1]][0] > 8_000_000]
 assert len(ends) >= 3, "need at least 3 optimizer launches in the trace"
+if rows[-1][0] - rows[ends[-1]][0] < 8_000_000 and len(adam) and adam[-1] != ends[-1]:
+    ends = ends[:-1] if len(ends) > 3 else ends       # the last step's deferred launches came from the final flush: use the one before
 i0, i1 = ends[-2] + 1, ends[-1] + 1
 step = rows[i0:i1]
 t0, t1 = step[0][0], step[-1][1]
