@@ -128,6 +128,22 @@ def side_stream(device) -> torch.cuda.Stream:
 
 _rejected_streams = {}
 _comm_streams = {}
+_flushers = []          # weak references to OrthoGradAdamW.flush_deferred of optimizers with updates deferred into the next forward
+
+
+def register_flusher(bound_method) -> None:
+    _flushers.append(weakref.WeakMethod(bound_method))
+
+
+def flush_deferred_updates() -> None:
+    """Complete every optimizer update still deferred into 'the next forward' (optim.OrthoGradAdamW.defer_into_next_forward) and
+    make the current stream wait for it: for code that reads parameters without running the model's forward (generate())."""
+    for r in list(_flushers):
+        f = r()
+        if f is None:
+            _flushers.remove(r)
+        else:
+            f(wait=True)
 
 
 def comm_stream(device) -> torch.cuda.Stream:

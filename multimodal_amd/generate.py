@@ -176,6 +176,7 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
     graph.CapturedTrainStep pays)."""
     dec = model.decoder
     dt = FN.get_compute_dtype()
+    FN.flush_deferred_updates()        # this loop reads the weights directly, not through model.forward (optim: deferred updates)
     was_training = model.training
     model.eval()
     dev = ir_data.device

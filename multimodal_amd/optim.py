@@ -201,6 +201,7 @@ class OrthoGradAdamW(torch.optim.Optimizer):
             m.register_forward_pre_hook(lambda mod, a, i=i: self._await_deferred(i))
         model.register_forward_hook(lambda m, a, o: self._await_deferred(None))
         model.register_state_dict_pre_hook(lambda *a, **k: self.flush_deferred(wait=True))
+        FN.register_flusher(self.flush_deferred)        # generate() reads the weights without a forward of `model`
 
     def _await_deferred(self, i):
         evs = getattr(self, "_defer_events", None)

@@ -81,3 +81,24 @@ def test_in_place_zero_grad_flushes_first():
         opt.zero_grad(set_to_none=False)                                           # the reference's OrthoGrad.zero_grad default
         torch.cuda.synchronize()
         assert opt._pending is None and not torch.equal(w.detach(), before)        # applied before the gradients were zeroed
+
+
+def test_generate_sees_the_deferred_update():
+    """generate() reads the decoder weights without running model.forward: pending updates must be applied first."""
+    import multimodal_amd as mm
+    from multimodal_amd.generate import greedy_generate
+    from multimodal_amd.optim import OrthoGradAdamW
+    outs = []
+    for defer in (False, True):
+        with mm.compute_dtype(torch.float32):
+            m = _model()
+            opt = OrthoGradAdamW(m.parameters(), lr=5e-2)
+            if defer:
+                opt.defer_into_next_forward(m, m.decoder.layers)
+            g = torch.Generator().manual_seed(1)
+            ir = torch.rand(2, 1000, generator=g).to(DEV); nmr = torch.randint(0, 50, (2, 16), generator=g).to(DEV)
+            tgt = torch.randint(5, 64, (2, 24), generator=g).to(DEV)
+            torch.nn.functional.cross_entropy(m(nmr, ir, tgt[:, :-1], None).reshape(-1, 64), tgt[:, 1:].reshape(-1)).backward()
+            opt.step()
+            outs.append(greedy_generate(m, nmr, ir, max_len=12).cpu())
+    assert torch.equal(outs[0], outs[1])
