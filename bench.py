@@ -720,7 +720,10 @@ def main():
                                    f"E{c['E']} H{c['H']} L{c['L']} {'stablemax' if c['sm'] else 'softmax'}, N={c['max_nmr']} "
                                    f"T={c['max_seq'] - 1} S={31 + c['max_nmr'] + c['max_seq'] - 1}",
                        "global_batch": gb, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
-                       "master_weights": "f32", "random_init": True},
+                       "master_weights": "f32", "random_init": True,
+                       "optimizer_updates": ("decoder layers deferred into the next forward (bit-identical, tests/"
+                                             "test_deferred_optimizer_gpu.py); the last one flushed inside the timed region")
+                       if getattr(opt, "_defer_ids", None) else "all inside opt.step()"},
             "mean_loss": round(final_loss, 4), "rccl_ranks": world if world > 1 else 0, "rccl": rccl,
         }
         out.update(extras)
