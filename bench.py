@@ -30,6 +30,8 @@ CONFIGS = {
 K1_PMC = os.path.join("profiles", "r02_k1_pmc.json")
 K4_PMC = os.path.join("profiles", "r02_k4_pmc.json")
 ATTN_PMC = os.path.join("profiles", "r02_attn3_pmc.json")
+ATTN_KERNELS = "attn_fwd3_k / attn_delta_k + attn_bwd_dq3_k + attn_bwd_dkv3_k"
+ATTN_KERNELS_WIDE = "prefix_attn_fwd_k / prefix_attn_bwd_dq4_k + prefix_attn_bwd_dkv4_k (head_dim > 192)"
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide)
 
@@ -201,13 +203,13 @@ def attn_roofline(device, B=32, H=16, d=100, N=190, T=94):
     fl = 4.0 * B * S * S * E
     af, ab = fl / tf / 1e12, 2.5 * fl / tb / 1e12
     counters = None
-    if os.path.exists(os.path.join(ROOT, ATTN_PMC)):           # rocprofv3 --pmc passes over benchmarks/attn_pmc.py, same shape
+    if (B, H, d) == (32, 16, 100) and os.path.exists(os.path.join(ROOT, ATTN_PMC)):           # rocprofv3 --pmc passes over benchmarks/attn_pmc.py, same shape
         with open(os.path.join(ROOT, ATTN_PMC)) as fh:
             pm = json.load(fh)
         counters = {"source": ATTN_PMC + " (not re-measured in this run)"}
         for kname, e in pm.items():
             counters[kname] = {k: v for k, v in e.items() if k != "counters_per_launch" and k != "kernel_name"}
-    return {"counters": counters, "kernel": "attn_fwd3_k / attn_delta_k + attn_bwd_dq3_k + attn_bwd_dkv3_k", "bound": "mfma", "unit": "TFLOP/s",
+    return {"counters": counters, "kernel": ATTN_KERNELS_WIDE if d > 192 else ATTN_KERNELS, "bound": "mfma", "unit": "TFLOP/s",
             "peak": MFMA_BF16_PEAK_TFLOPS, "achieved": round(af, 1), "frac": round(af / MFMA_BF16_PEAK_TFLOPS, 4),
             "launch_us": round(tf * 1e6, 1), "bwd_achieved": round(ab, 1), "bwd_frac": round(ab / MFMA_BF16_PEAK_TFLOPS, 4),
             "bwd_launch_us": round(tb * 1e6, 1), "traffic": None,
@@ -400,7 +402,30 @@ def greedy_nocache(device, B=128):
             "recompute_tokens_per_s": round(B * steps / t_nocache, 1), "speedup": round(t_nocache / t_cache, 2)}
 
 
-def cpu_baseline(c, sample_b=32, timed=3):
+def test_config_leg(device, B=8):
+    """BASELINE.json configs[0] (configs/test_config.yaml, E768 H4 L8 stablemax, batch 8): one forward over the full
+    sequence and one KV-cached greedy decode of max_seq steps, fp32 (exact-f32 kernels: the path on which ids equal the
+    reference's).  The reference runs this case on the CPU; here it is the same plumbing on the HIP path."""
+    import multimodal_amd as mm
+    c = CONFIGS["test_config"]
+    m = build_model(c, device).eval()
+    ir, nmr, tgt = synth_batch(c, B, device, 2024)
+    steps = c["max_seq"]
+    with mm.compute_dtype(torch.float32), torch.no_grad():
+        tf = _event_time(lambda: m(nmr, ir, tgt[:, :-1], None), iters=5, warmup=2)
+        m.generate(nmr, ir, max_len=steps, early_stop=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        toks = m.generate(nmr, ir, max_len=steps, early_stop=False)
+        torch.cuda.synchronize()
+        tg = time.perf_counter() - t0
+    return {"config": "configs/test_config.yaml (E768 H4 d192 L8 stablemax)", "batch": B, "dtype": "float32",
+            "forward_ms": round(tf * 1e3, 3), "forward_spectra_per_s": round(B / tf, 1),
+            "greedy_steps": int(toks.shape[1] - 1), "greedy_seconds": round(tg, 4),
+            "greedy_tokens_per_s": round(B * (toks.shape[1] - 1) / tg, 1)}
+
+
+def cpu_baseline(c, sample_b=32, timed=3, warm=1):
     """The CPU oracle (oracle/restate.py, pinned against the reference) timed on the host cores: the train step
     (forward + CE + backward + OrthoGrad + AdamW) of the same shape at the config batch, one warm-up + `timed` steps."""
     from oracle import restate
@@ -433,7 +458,8 @@ def cpu_baseline(c, sample_b=32, timed=3):
         loss.backward()
         restate.orthograd_project_(params, eps=1e-8)
         opt.step()
-    step()                                            # warm-up (allocator, thread pool, oneDNN primitive caches)
+    for _ in range(warm):                             # warm-up (allocator, thread pool, oneDNN primitive caches)
+        step()
     times = []
     for _ in range(timed):
         t0 = time.perf_counter()
@@ -450,7 +476,7 @@ def cpu_baseline(c, sample_b=32, timed=3):
             "host_cpus_visible": os.cpu_count(),
             "cores_note": "threads = the box's CPU share per GPU (OMP_NUM_THREADS as set by the pool), not the whole host",
             "step_seconds": [round(t, 2) for t in times],
-            "sample": f"1 warm-up + {timed} timed train steps (fwd+CE+bwd+OrthoGrad+AdamW), median, fp32, local_config "
+            "sample": f"{warm} warm-up + {timed} timed train steps (fwd+CE+bwd+OrthoGrad+AdamW), median, fp32, local_config "
                       f"shape, batch {sample_b}, N=190 T=94, {dt:.1f} s per step"}
 
 
@@ -471,7 +497,7 @@ def spawn_ranks(a, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
-def dry_run(a, world, rank):
+def dry_run(a, world, rank, json_out=sys.stdout):
     """--dry-run: the launch / rendezvous / exchange plumbing without a GPU (backend gloo, CPU tensors): each rank runs the
     production DataParallel wrapper (buckets, hook-driven all-reduce, finish) around a small stand-in module, and rank 0
     prints a JSON line of the same form.  Covers `--gpus N` in the CPU test-suite; measures nothing."""
@@ -510,7 +536,7 @@ def dry_run(a, world, rank):
         print(json.dumps({"metric": "train spectra/sec", "value": None, "unit": "spectra/s", "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "dry_run": True, "backend": a.backend, "rccl_ranks": world,
                           "allreduce_calls": dp.n_allreduce if dp else 0, "replicas_equal": True,
-                          "per_rank_ms_per_step": [round(t / max(1, a.steps) * 1e3, 3) for t in per_rank]}), flush=True)
+                          "per_rank_ms_per_step": [round(t / max(1, a.steps) * 1e3, 3) for t in per_rank]}), file=json_out, flush=True)
 
 
 def rccl_world1_leg(c, device, steps=5):
@@ -568,6 +594,97 @@ def rccl_world1_leg(c, device, steps=5):
     return out
 
 
+def run_leg(extras, key, fn, *args, **kw):
+    """One extra leg: a Python-level failure in it is recorded under its key (and on stderr) instead of costing the whole
+    line; the headline value, measured before any extra leg, is printed whatever happens here."""
+    import traceback
+    try:
+        extras[key] = fn(*args, **kw)
+    except Exception as ex:                                   # noqa: BLE001 -- the line must survive any leg
+        traceback.print_exc(file=sys.stderr)
+        extras[key] = {"error": f"{type(ex).__name__}: {ex}"}
+        log(f"leg {key} FAILED: {extras[key]['error']}")
+    try:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    except Exception:                                         # noqa: BLE001
+        pass
+    return extras[key]
+
+
+def run_extras(a, c, device, world, rank):
+    """Roofline, greedy, other-config and CPU-baseline legs of the JSON line (each one guarded by run_leg)."""
+    import torch.distributed as dist
+    q = a.quick
+    extras = {}
+    roof = run_leg(extras, "roofline", k1_roofline, device)
+    run_leg(extras, "roofline_bf16", k1_roofline, device, torch.bfloat16)
+    lat = run_leg({}, "lat", k1_roofline, device, torch.float32, B=32, iters=50)
+    if "error" not in roof and "error" not in lat:
+        roof["config_batch_latency_us"] = lat["launch_us"]
+    log("K1 roofline done; greedy leg")
+    greedy = run_leg(extras, "greedy", greedy_bench, device, world, rank)
+    if "error" not in greedy:
+        if world > 1:
+            gt = torch.tensor([greedy["tokens_per_s_per_gpu"]], device=device, dtype=torch.float64)
+            dist.all_reduce(gt, op=dist.ReduceOp.SUM)
+            greedy["tokens_per_s"] = round(float(gt.item()), 1)
+        else:
+            greedy["tokens_per_s"] = greedy["tokens_per_s_per_gpu"]
+    run_leg(extras, "roofline_mfma", gemm_roofline, device)
+    run_leg(extras, "roofline_k2", k2_roofline, device)
+    run_leg(extras, "roofline_attn", attn_roofline, device)
+    run_leg(extras, "roofline_attn_d512", attn_roofline, device, B=32, H=4, d=512)
+    run_leg(extras, "roofline_decode", decode_roofline, device)
+    run_leg(extras, "roofline_k1_all_shapes", k1_all_shapes, device)
+    log("kernel rooflines done")
+    if world == 1:
+        run_leg(extras, "greedy_vs_recompute", greedy_nocache, device)
+        log("greedy recompute leg done; batch-256, fp32, own-back-end, real_config_mup and test_config legs")
+        run_leg(extras, "train_batch256_bf16", train_leg, c, device, 256, torch.bfloat16, steps=2 if q else 4, warmup=1 if q else 2)
+        run_leg(extras, "train_batch32_fp32", train_leg, c, device, 32, torch.float32, steps=2 if q else 5, warmup=1 if q else 2)
+        own = run_leg(extras, "train_own_gemms_bf16", train_leg, c, device, a.batch, torch.bfloat16, steps=2 if q else 10,
+                      warmup=1 if q else 3, backend="own")
+        own["note"] = ("every dense product of the step on libmmhip (MM_GEMM_BACKEND=own): no hipBLASLt kernel on the path; "
+                       "the headline uses the per-product faster one")
+        # BASELINE.json configs[4]: the widened muP model (E2048 H4 d512 L8), same step, config batch
+        mup = run_leg(extras, "train_real_config_mup_bf16", train_leg, CONFIGS["real_config_mup"], device, 32, torch.bfloat16,
+                      steps=2 if q else 8, warmup=1 if q else 3)
+        mup["config"] = "configs/real_config_mup.yaml (E2048 H4 d512 L8 stablemax, N=190 T=94 S=315)"
+        # BASELINE.json configs[0]: test_config, batch 8, forward + greedy decode (fp32: the path whose ids equal the reference's)
+        run_leg(extras, "test_config_forward_greedy", test_config_leg, device)
+        log("captured-step leg")
+        run_leg(extras, "hip_graph_step", graph_leg, device, steps=3 if q else 20)
+        log("RCCL one-rank leg")
+        run_leg(extras, "rccl_world1", rccl_world1_leg, c, device, steps=2 if q else 5)
+    if rank == 0 and world == 1:
+        log("CPU baseline (oracle, train steps on the host cores)")
+        run_leg(extras, "cpu_baseline", cpu_baseline, c, sample_b=a.cpu_batch, timed=a.cpu_steps, warm=0 if q else 1)
+        log("CPU baseline done")
+    return extras
+
+
+def assemble_line(a, c, world, elapsed, final_loss, rccl, opt_updates, extras):
+    """The ONE JSON line (rank 0).  Takes plain values only, so tests/test_bench_cpu.py can call it without a GPU."""
+    gb = a.batch * world
+    out = {
+        "metric": "train spectra/sec", "value": round(gb * a.steps / elapsed, 2), "unit": "spectra/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"configs/{a.config}.yaml train step (fwd + CE + bwd + grad all-reduce + OrthoGrad-AdamW), "
+                               f"E{c['E']} H{c['H']} L{c['L']} {'stablemax' if c['sm'] else 'softmax'}, N={c['max_nmr']} "
+                               f"T={c['max_seq'] - 1} S={31 + c['max_nmr'] + c['max_seq'] - 1}",
+                   "global_batch": gb, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
+                   "master_weights": "f32", "random_init": True, "optimizer_updates": opt_updates},
+        "mean_loss": round(final_loss, 4), "rccl_ranks": world if world > 1 else 0, "rccl": rccl,
+    }
+    out.update(extras)
+    failed = sorted(k for k, v in extras.items() if isinstance(v, dict) and "error" in v)
+    if failed:
+        out["failed_legs"] = failed
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -577,6 +694,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (configs/*.yaml: training.batch_size = 32)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / greedy / cpu baseline legs")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed train steps of the CPU baseline (about 13 s each at batch 32)")
+    ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU baseline's sample (config batch = 32)")
+    ap.add_argument("--quick", action="store_true",
+                    help="every extra leg at its smallest step count (tests/test_bench_gpu.py: the whole default path in seconds)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend: nccl (= RCCL, the product path) or gloo (CPU plumbing check, --dry-run)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous + DataParallel plumbing on CPU tensors, no GPU, no timing")
@@ -585,6 +706,12 @@ def main():
     import torch.distributed as dist
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(a, sys.argv[1:]))
+    # stdout carries exactly ONE line, the JSON: native libraries (RCCL's version banner) write to file descriptor 1 behind
+    # Python's back, so fd 1 is pointed at stderr for the whole run and the line goes out through a saved copy of it
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    json_out = os.fdopen(json_fd, "w")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -596,7 +723,7 @@ def main():
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world)
             assert dist.get_world_size() == a.gpus
-        dry_run(a, world, rank)
+        dry_run(a, world, rank, json_out)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -673,61 +800,20 @@ def main():
             "buckets": len(dp.buckets.buckets), "bucket_mib": [round(b["flat"].numel() * 4 / 2 ** 20, 1) for b in dp.buckets.buckets],
             "per_rank_ms_per_step": [round(t / a.steps * 1e3, 3) for t in per_rank]}
 
+    # everything the JSON line says about the optimizer is read BEFORE the objects go away (round 2 lost its whole line to a
+    # read of `opt` after `del opt`)
+    opt_updates = ("decoder layers deferred into the next forward (bit-identical, tests/test_deferred_optimizer_gpu.py); "
+                   "the last one flushed inside the timed region") if getattr(opt, "_defer_ids", None) else "all inside opt.step()"
     extras = {}
     if not a.no_extras:
-        del opt, dp
+        del opt, dp, step
         model = None
         torch.cuda.empty_cache()
-        roof = k1_roofline(device)
-        roof_bf16 = k1_roofline(device, torch.bfloat16)
-        log("K1 roofline done; greedy leg")
-        greedy = greedy_bench(device, world, rank)
-        if world > 1:
-            gt = torch.tensor([greedy["tokens_per_s_per_gpu"]], device=device, dtype=torch.float64)
-            dist.all_reduce(gt, op=dist.ReduceOp.SUM)
-            greedy["tokens_per_s"] = round(float(gt.item()), 1)
-        else:
-            greedy["tokens_per_s"] = greedy["tokens_per_s_per_gpu"]
-        extras = {"roofline": roof, "roofline_bf16": roof_bf16, "roofline_mfma": gemm_roofline(device),
-                  "roofline_k2": k2_roofline(device), "roofline_attn": attn_roofline(device), "roofline_decode": decode_roofline(device), "greedy": greedy}
-        extras["roofline"]["config_batch_latency_us"] = k1_roofline(device, torch.float32, B=32, iters=50)["launch_us"]
-        extras["roofline_k1_all_shapes"] = k1_all_shapes(device)
-        log("kernel rooflines done")
-        if world == 1:
-            extras["greedy_vs_recompute"] = greedy_nocache(device)
-            log("greedy recompute leg done; batch-256 and fp32 train legs")
-            extras["train_batch256_bf16"] = train_leg(c, device, 256, torch.bfloat16, steps=4, warmup=2)
-            extras["train_batch32_fp32"] = train_leg(c, device, 32, torch.float32, steps=5, warmup=2)
-            extras["train_own_gemms_bf16"] = train_leg(c, device, a.batch, torch.bfloat16, steps=10, warmup=3, backend="own")
-            extras["train_own_gemms_bf16"]["note"] = ("every dense product of the step on libmmhip (MM_GEMM_BACKEND=own): no "
-                                                      "hipBLASLt kernel on the path; the headline uses the per-product faster one")
-            log("captured-step leg")
-            extras["hip_graph_step"] = graph_leg(device)
-            log("RCCL one-rank leg")
-            extras["rccl_world1"] = rccl_world1_leg(c, device)
-        if rank == 0 and world == 1:
-            log("CPU baseline (oracle, train steps on the host cores)")
-            extras["cpu_baseline"] = cpu_baseline(c)
-            log("CPU baseline done")
+        extras = run_extras(a, c, device, world, rank)
 
     if rank == 0:
-        gb = a.batch * world
-        out = {
-            "metric": "train spectra/sec", "value": round(gb * a.steps / elapsed, 2), "unit": "spectra/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"configs/{a.config}.yaml train step (fwd + CE + bwd + grad all-reduce + OrthoGrad-AdamW), "
-                                   f"E{c['E']} H{c['H']} L{c['L']} {'stablemax' if c['sm'] else 'softmax'}, N={c['max_nmr']} "
-                                   f"T={c['max_seq'] - 1} S={31 + c['max_nmr'] + c['max_seq'] - 1}",
-                       "global_batch": gb, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
-                       "master_weights": "f32", "random_init": True,
-                       "optimizer_updates": ("decoder layers deferred into the next forward (bit-identical, tests/"
-                                             "test_deferred_optimizer_gpu.py); the last one flushed inside the timed region")
-                       if getattr(opt, "_defer_ids", None) else "all inside opt.step()"},
-            "mean_loss": round(final_loss, 4), "rccl_ranks": world if world > 1 else 0, "rccl": rccl,
-        }
-        out.update(extras)
-        print(json.dumps(out), flush=True)
+        out = assemble_line(a, c, world, elapsed, final_loss, rccl, opt_updates, extras)
+        print(json.dumps(out), file=json_out, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

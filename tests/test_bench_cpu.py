@@ -50,3 +50,23 @@ def test_world_size_must_match_gpus():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--backend", "gloo", "--dry-run"], capture_output=True, text=True,
                        timeout=120, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_json_line_assembly_without_gpu():
+    """The JSON line is assembled from plain values (round 2 lost its line to a read of a deleted object): the
+    assembly, with a failed leg recorded, must serialise and carry the contract's keys."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    a = argparse.Namespace(batch=32, steps=20, warmup=5, dtype="bf16", config="local_config")
+    extras = {}
+    bench.run_leg(extras, "roofline", lambda: {"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1,
+                                                 "traffic": None})
+    bench.run_leg(extras, "broken", lambda: 1 / 0)
+    out = bench.assemble_line(a, bench.CONFIGS["local_config"], 1, 0.5, 6.9, {"ranks": 1}, "all inside opt.step()", extras)
+    line = json.loads(json.dumps(out))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert line["value"] == 1280.0 and line["ms_per_step"] == 25.0 and "workload" in line["config"]
+    assert line["failed_legs"] == ["broken"] and "ZeroDivisionError" in line["broken"]["error"]
