@@ -87,6 +87,12 @@ class _StepPlan:
         logits = new(B, V)
         self.keep = [x0, x1, xa, qkv, att, xf, u, logits, weights, w_out, b_out, b_out16, emb_dt, ids, cache]
         self.x0, self.emb, self.ids = x0, emb_dt, ids
+        # K-split workspace of the skinny, deep products (both have K = E): ONE buffer owned by this plan, sized for the
+        # largest of them before any argument list takes its address (a grow-only shared workspace would be replaced -- and
+        # the first product's slabs written into freed memory -- when a later product asks for more)
+        needs = [8 * B * n * 4 for n in (E, F4) if bf and B * n <= (1 << 22) and E >= 2048]
+        ws = torch.empty(max(needs), dtype=torch.uint8, device=dev) if needs else None
+        self.keep.append(ws)
         calls = []                              # (callable, args) ; args None -> plain Python callable
         self.k4 = []                            # indices of the K4 entries (their position argument changes per step)
 
@@ -104,7 +110,7 @@ class _StepPlan:
             g.res = res.data_ptr() if res is not None else None
             g.split_k = 1
             if bf and g.M * g.N <= (1 << 22) and g.K >= 2048:      # skinny and deep: room for the library's own K split
-                ws = ops.workspace(8 * g.M * g.N * 4, dev, "gemm_auto")
+                assert ws is not None and ws.numel() >= 8 * g.M * g.N * 4
                 g.workspace, g.workspace_bytes = ws.data_ptr(), 8 * g.M * g.N * 4
             self.keep.append(g)
             calls.append((lib.mm_gemm, "mm_gemm", [C.byref(g), st]))

@@ -191,16 +191,27 @@ class OrthoGradAdamW(torch.optim.Optimizer):
         (model.decoder.layers).  Everything else is updated inside step() as before.  Hooks on `model` launch / await the
         updates; state_dict() of the model or of this optimizer, zero_grad() of this optimizer and flush_deferred() complete
         them first.  Gradients must not be zeroed IN PLACE between step() and the next forward (DataParallel.zero_grad and
-        zero_grad(set_to_none=True) only drop the references, which step() keeps)."""
+        zero_grad(set_to_none=True) only drop the references, which step() keeps).  Code that reads the deferred parameters
+        through `parameters()` between step() and the next forward (an EMA, a weight-norm log) calls flush_deferred(wait=True)
+        first: a raw tensor read cannot be hooked."""
         self._defer_layers = [[p for p in m.parameters()] for m in layer_modules]
         self._defer_ids = set(id(p) for ps in self._defer_layers for p in ps)
         self._pending = None
         self._defer_events = {}
-        model.register_forward_pre_hook(lambda m, a: self.flush_deferred())
+        # every module that holds a deferred parameter -- the model, the decoder, the layers, their children -- completes the
+        # pending updates before its state_dict() is read; every strict ancestor of the layers launches them at the top of
+        # its forward (a loop may call model.decoder directly) and joins what is left when its forward returns
+        layer_ids = set(id(m) for m in layer_modules)
+        inside = set(id(sub) for m in layer_modules for sub in m.modules())
+        for mod in model.modules():
+            if not any(id(p) in self._defer_ids for p in mod.parameters()):
+                continue
+            mod.register_state_dict_pre_hook(lambda *a, **k: self.flush_deferred(wait=True))
+            if id(mod) not in inside:
+                mod.register_forward_pre_hook(lambda m, a: self.flush_deferred())
+                mod.register_forward_hook(lambda m, a, o: self._await_deferred(None))
         for i, m in enumerate(layer_modules):
             m.register_forward_pre_hook(lambda mod, a, i=i: self._await_deferred(i))
-        model.register_forward_hook(lambda m, a, o: self._await_deferred(None))
-        model.register_state_dict_pre_hook(lambda *a, **k: self.flush_deferred(wait=True))
         FN.register_flusher(self.flush_deferred)        # generate() reads the weights without a forward of `model`
 
     def _await_deferred(self, i):
@@ -262,10 +273,13 @@ class OrthoGradAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if getattr(self, "_pending", None):
+            # a step with no forward since the last one: the older update is still pending (and left the step open).  Apply
+            # it first, in order, then open the new step
+            self.flush_deferred()
         begun = getattr(self, "_begun", False)
         capturing = self.capturable and torch.cuda.is_current_stream_capturing()
         if getattr(self, "_defer_ids", None) and not begun and not capturing and not self.capturable:
-            self.flush_deferred()                       # a step without a forward in between: apply the older update first
             FN.join_side_stream()
             self.begin_step()
             early, late_missing = [], []
@@ -326,7 +340,9 @@ class OrthoGradAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         """Accepts this class's state_dict() and the reference's OrthoGrad(AdamW) checkpoints (same layout; its groups
-        carry one 'eps' for both the projection and AdamW and no 'ortho*' keys).  The caller's dict is not modified."""
+        carry one 'eps' for both the projection and AdamW and no 'ortho*' keys).  The caller's dict is not modified.
+        Pending deferred updates are completed first (on the moments they were computed for), not on the loaded ones."""
+        self.flush_deferred(wait=True)
         base = state_dict.get("base_optimizer")
         if base is not None:
             state, groups = base["state"], (state_dict.get("param_groups") or base["param_groups"])

@@ -102,3 +102,93 @@ def test_generate_sees_the_deferred_update():
             opt.step()
             outs.append(greedy_generate(m, nmr, ir, max_len=12).cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+def _one_backward(m, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    ir = torch.rand(2, 1000, generator=g).to(DEV); nmr = torch.randint(0, 50, (2, 16), generator=g).to(DEV)
+    tgt = torch.randint(5, 64, (2, 24), generator=g).to(DEV)
+    torch.nn.functional.cross_entropy(m(nmr, ir, tgt[:, :-1], None).reshape(-1, 64), tgt[:, 1:].reshape(-1)).backward()
+    return nmr, ir, tgt
+
+
+def test_two_steps_without_a_forward_between_them():
+    """step(); step() with the same gradients: the older (pending) update is applied first, in order, then the new step is
+    opened -- parameters and moments bit-identical to the plain optimizer doing the same."""
+    import multimodal_amd as mm
+    from multimodal_amd.optim import OrthoGradAdamW
+    res = []
+    for defer in (False, True):
+        with mm.compute_dtype(torch.float32):
+            m = _model()
+            opt = OrthoGradAdamW(m.parameters(), lr=1e-2, eps=1e-8, ortho_eps=1e-8)
+            if defer:
+                opt.defer_into_next_forward(m, m.decoder.layers)
+            _one_backward(m)
+            opt.step()
+            for grp in opt.param_groups:
+                grp["lr"] = 3e-3
+            opt.step()
+            opt.step()
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+            res.append((sd, copy.deepcopy(opt.state_dict())))
+    (sd0, o0), (sd1, o1) = res
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+    s0, s1 = o0["base_optimizer"]["state"], o1["base_optimizer"]["state"]
+    for i in s0:
+        for kk in ("exp_avg", "exp_avg_sq", "step"):
+            assert torch.equal(s0[i][kk], s1[i][kk]), (i, kk)
+
+
+def test_submodule_state_dict_and_direct_decoder_call_complete_the_update():
+    import multimodal_amd as mm
+    from multimodal_amd.optim import OrthoGradAdamW
+    outs = []
+    for defer in (False, True):
+        with mm.compute_dtype(torch.float32):
+            m = _model()
+            opt = OrthoGradAdamW(m.parameters(), lr=1e-2)
+            if defer:
+                opt.defer_into_next_forward(m, m.decoder.layers)
+            nmr, ir, tgt = _one_backward(m)
+            opt.step()
+            if defer:
+                assert opt._pending is not None
+            with torch.no_grad():
+                mem = m.encoder(None, ir, None)
+                lg = m.decoder(tgt[:, :5], mem, nmr)                # not through model.forward
+            torch.cuda.synchronize()
+            assert getattr(opt, "_pending", None) is None
+            _one_backward(m, seed=2)
+            opt.step()
+            sd_layer = {k: v.clone() for k, v in m.decoder.layers[1].state_dict().items()}   # a layer's own state_dict()
+            sd_dec = {k: v.clone() for k, v in m.decoder.state_dict().items()}
+            outs.append((lg.clone(), sd_layer, sd_dec))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in ((outs[0][1], outs[1][1]), (outs[0][2], outs[1][2])):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
+def test_load_state_dict_completes_pending_updates_first():
+    import multimodal_amd as mm
+    from multimodal_amd.optim import OrthoGradAdamW
+    with mm.compute_dtype(torch.float32):
+        m = _model()
+        opt = OrthoGradAdamW(m.parameters(), lr=1e-2)
+        opt.defer_into_next_forward(m, m.decoder.layers)
+        _one_backward(m)
+        opt.step()
+        saved = copy.deepcopy(opt.state_dict())          # completes the update; moments after step 1
+        w = m.decoder.layers[0].q.weight
+        _one_backward(m, seed=3)
+        opt.step()
+        assert opt._pending is not None
+        before = w.detach().clone()
+        opt.load_state_dict(saved)
+        torch.cuda.synchronize()
+        assert opt._pending is None and not torch.equal(w.detach(), before)      # step 2 landed, on ITS moments ...
+        st = opt.state[w]
+        i = [p for g in opt.param_groups for p in g["params"]].index(w)
+        assert torch.equal(st["exp_avg"], saved["base_optimizer"]["state"][i]["exp_avg"].to(DEV))   # ... not on the loaded ones
