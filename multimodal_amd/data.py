@@ -40,13 +40,18 @@ def load_vocabularies(tokenized_dir, smiles_tokenizer):
 
 
 def _open_ir(data_dir: Path, split: str, num_samples: int):
+    """train_autoregressive.py:264-287: any failure while opening or reshaping the raw float32 file is a printed warning and
+    training goes on without IR (`ir_data = None`) -- including a float count that does not divide into the samples, which
+    numpy's reshape refuses there exactly as it does here."""
     path = data_dir / f"ir-{split}.npy"
-    if not path.exists() or num_samples == 0:
+    if not path.exists():
         return None
-    flat = np.memmap(path, dtype="float32", mode="r")             # raw floats: the file has no .npy header
-    if flat.shape[0] % num_samples:
-        raise ValueError(f"{path}: {flat.shape[0]} floats do not divide into {num_samples} samples")
-    return flat.reshape(num_samples, flat.shape[0] // num_samples)
+    try:
+        flat = np.memmap(path, dtype="float32", mode="r")         # raw floats: the file has no .npy header
+        return flat.reshape(num_samples, flat.shape[0] // num_samples)
+    except Exception as e:                                        # noqa: BLE001 -- the reference catches everything here
+        print(f"[Warning] Failed to load IR data: {e}")
+        return None
 
 
 class SpectralSmilesDataset(torch.utils.data.Dataset):
@@ -228,8 +233,10 @@ class PinnedBatchLoader:
             hs = sets[k]
             if self.cuda:
                 with torch.cuda.stream(copy_stream):
-                    tgt = hs["tgt"][:b, :tw].to(self.device, non_blocking=True)
-                    nmr = hs["nmr"][:b, :sw].to(self.device, non_blocking=True)
+                    # whole pinned rows (contiguous: a truly asynchronous copy), cut to the batch's width on the device; a
+                    # [:b, :tw] slice of the pinned buffer would first be gathered into a pageable temporary on the host
+                    tgt = hs["tgt"][:b].to(self.device, non_blocking=True)[:, :tw].contiguous()
+                    nmr = hs["nmr"][:b].to(self.device, non_blocking=True)[:, :sw].contiguous()
                     ir = None if hs["ir"] is None else hs["ir"][:b].to(self.device, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(copy_stream)

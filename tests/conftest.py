@@ -16,6 +16,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+ACHIEVED = []          # (test, text): achieved errors of the parity tests, printed in the terminal summary of every run
+
+
+def report(*parts):
+    """Record achieved errors for the run's log (pytest hides a passing test's stdout): shown under 'achieved errors'."""
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0].split("::", 1)[-1]
+    ACHIEVED.append((test, " ".join(f"{x:.3g}" if isinstance(x, float) else str(x) for x in parts)))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if ACHIEVED:
+        terminalreporter.section("achieved errors (parity tests)")
+        for test, text in ACHIEVED:
+            terminalreporter.write_line(f"{test}: {text}")
+
+
 def pytest_collection_modifyitems(config, items):
     if torch.cuda.is_available():
         return

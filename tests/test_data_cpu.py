@@ -103,3 +103,16 @@ def test_missing_ir_file_and_drop_last(data_dir):
     assert ds[0][1] == (None, None)
     batches = list(PinnedBatchLoader(ds, 4, drop_last=True))
     assert len(batches) == len(SMILES) // 4 and all(b[1] is None and b[0].shape[0] == 4 for b in batches)
+
+
+def test_unreadable_ir_file_is_a_warning_not_a_crash(data_dir, capsys):
+    """train_autoregressive.py:285-287: a float count that does not divide into the samples (numpy's reshape raises) is
+    caught, warned about, and training goes on with ir_data = None."""
+    from multimodal_amd.data import SpectralSmilesDataset, load_vocabularies
+    with open(data_dir / "ir-train.npy", "ab") as fh:
+        fh.write(np.zeros(7, dtype=np.float32).tobytes())
+    tok = _tok()
+    _, _, nmr_vocab = load_vocabularies(data_dir, tok)
+    ds = SpectralSmilesDataset(data_dir, tok, nmr_vocab)
+    assert ds.ir_data is None and ds[0][1] == (None, None)
+    assert "[Warning] Failed to load IR data" in capsys.readouterr().out

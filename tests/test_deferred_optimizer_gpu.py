@@ -190,5 +190,5 @@ def test_load_state_dict_completes_pending_updates_first():
         torch.cuda.synchronize()
         assert opt._pending is None and not torch.equal(w.detach(), before)      # step 2 landed, on ITS moments ...
         st = opt.state[w]
-        i = [p for g in opt.param_groups for p in g["params"]].index(w)
+        i = next(j for j, p in enumerate(p for g in opt.param_groups for p in g["params"]) if p is w)
         assert torch.equal(st["exp_avg"], saved["base_optimizer"]["state"][i]["exp_avg"].to(DEV))   # ... not on the loaded ones
