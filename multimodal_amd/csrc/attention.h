@@ -17,3 +17,8 @@ struct AttnP {
 bool attn_fast_ok(const AttnP& p);
 int attn_fast_fwd(const AttnP& p, int mode, hipStream_t st);
 int attn_fast_bwd(const AttnP& p, int mode, hipStream_t st);      // dq and dk/dv kernels (delta already computed)
+
+// bf16 forms for head_dim = 512 (attention_wide.hip): pre-rotated q,k, 16-byte aligned rows; DMA-staged tiles, one wave per SIMD.
+bool attn_wide_ok(const AttnP& p);
+int attn_wide_fwd(const AttnP& p, int mode, hipStream_t st);
+int attn_wide_bwd(const AttnP& p, int mode, hipStream_t st);      // dq and dk/dv kernels (delta already computed)

@@ -536,8 +536,10 @@ extern "C" int mm_prefix_attn_fwd(const void* q, const void* k, const void* v, v
     hipStream_t st = (hipStream_t)stream;
     static const bool force_generic = getenv("MM_ATTN_GENERIC") != nullptr;     // A/B switch for debugging
     static const bool force_v2 = getenv("MM_ATTN_V2") != nullptr;               // A/B switch: the previous fast generation
+    static const bool no_wide = getenv("MM_ATTN_NO_WIDE") != nullptr;           // A/B switch: head_dim 512 on the staged kernels
     if (!force_generic && dtype == MM_BF16 && rot == 0 && p.vec_ok && ((uintptr_t)o) % 8 == 0) {
         if (!force_v2 && attn_fast_ok(p)) return attn_fast_fwd(p, mode, st);
+        if (!force_v2 && !no_wide && attn_wide_ok(p)) return attn_wide_fwd(p, mode, st);     // head_dim 512
         return fwd2_dispatch(p, mode, st);
     }
     return dtype == MM_BF16 ? fwd_dispatch<bf16>(p, mode, st) : fwd_dispatch<float>(p, mode, st);
@@ -1518,6 +1520,10 @@ extern "C" int mm_prefix_attn_bwd(const void* q, const void* k, const void* v, c
         if (!force_v2 && attn_fast_ok(p)) return attn_fast_bwd(p, mode, st);
         return bwd_dispatch5(p, mode, st);
     }
+    static const bool no_wide = getenv("MM_ATTN_NO_WIDE") != nullptr;           // A/B switch: head_dim 512 on the staged kernels
+    if (!force_generic && !force_v2 && !no_wide && dtype == MM_BF16 && rot == 0 && p.vec_ok && al8 && attn_wide_ok(p) &&
+        ((uintptr_t)d_o) % 16 == 0)
+        return attn_wide_bwd(p, mode, st);                                      // head_dim 512: DMA-staged, one wave per SIMD
     return dtype == MM_BF16 ? bwd_dispatch4(p, mode, st) : bwd_dispatch<float>(p, mode, st);
 }
 

@@ -28,6 +28,9 @@ def _oracle(q, k, v, H, rot, P, stablemax):
 CASES = [  # B, H, d, S, P
     (2, 4, 32, 33, 21), (2, 2, 100, 47, 38), (1, 2, 128, 150, 100), (2, 2, 192, 70, 36), (1, 2, 512, 40, 36),
     (1, 16, 100, 315, 221), (2, 3, 64, 17, 0), (1, 1, 32, 5, 5), (3, 2, 128, 65, 64),
+    # head_dim 512 (attention_wide.hip on the pre-rotated bf16 path): the real_config_mup sequence, a causal-only head,
+    # lengths that are / are not multiples of the 32-row tiles and of the 64-row workgroup blocks
+    (1, 2, 512, 315, 221), (2, 1, 512, 130, 0), (1, 1, 512, 64, 64), (1, 3, 512, 97, 33),
 ]
 
 
