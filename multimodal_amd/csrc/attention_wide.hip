@@ -46,13 +46,110 @@ __device__ __forceinline__ void stage_pair(const bf16* a, long lda, const bf16* 
     for (int i = 0; i < WT / 4; i++) {
         const int r = wave + 4 * i;
         const int gr = min(row0 + r, S - 1);
-        dma_row(uniform_ptr(a + (long)gr * lda), base + (unsigned)(r * WP * 2), lane16);
-        dma_row(uniform_ptr(b + (long)gr * ldb), base + (unsigned)((WTILE + r * WP) * 2), lane16);
+        dma_row(a + (long)gr * lda, base + (unsigned)(r * WP * 2), lane16);
+        dma_row(b + (long)gr * ldb, base + (unsigned)((WTILE + r * WP) * 2), lane16);
     }
 }
 __device__ __forceinline__ void wait_tile() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+}
+
+
+// ---- MFMA with the register file of every operand chosen by hand ---------------------------------------------------------
+// Left to the compiler, these kernels either copied all 128 loop-carried accumulators AGPR -> VGPR -> AGPR around every tile
+// step (AGPR form: 714 v_accvgpr moves in the dQ kernel), or (VGPR form) filled the 256 VGPRs with stationary state and read
+// every LDS fragment just before its use, two at a time, with the LDS latency exposed 48 times a step.  Here the stationary
+// fragments (B operands of the scores phase, loop-invariant) live in AGPRs by constraint, which leaves VGPRs for the streamed
+// fragments: they are read a chunk ahead (double-buffered in registers) behind sched_barriers.  The compiler does not know these
+// instructions, so the waits its hazard recognizer would add after an MFMA are written out (s_nop) where a VALU instruction
+// or an accumulator read follows one.
+__device__ __forceinline__ void mfma_v0(f32x4_t& acc, const bf16x8_t a, const bf16x8_t& b_acc) {      // acc(VGPR) = a . b
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b_acc));
+}
+__device__ __forceinline__ void mfma_v(f32x4_t& acc, const bf16x8_t a, const bf16x8_t& b_acc) {       // acc(VGPR) += a . b
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b_acc));
+}
+// The OUTPUT accumulators are loop-carried: a value that flows through a loop phi is given the VGPR class whatever asm
+// constraints its uses carry (an "+a" accumulator was copied VGPR -> AGPR -> VGPR around every chunk: 256 moves per step), so
+// they stay in VGPRs through the compiler's own VGPR-form MFMA (Makefile: -amdgpu-mfma-vgpr-form=1), 128 of the 256.
+__device__ __forceinline__ void mfma_out(f32x4_t& acc, const bf16x8_t a, const bf16x8_t b) {          // acc(VGPR, loop-carried) += a . b
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+// a stationary fragment becomes ONE aligned 4-register AGPR tuple here, once (assembled from two 8-byte loads it otherwise sat
+// in scattered registers and every use rebuilt the tuple with four v_accvgpr_mov)
+__device__ __forceinline__ void pin_acc(bf16x8_t& f) { asm volatile("" : "+a"(f)); }
+// MFMA result -> VALU read: 24 wait states, written out because the hazard recognizer does not see an MFMA inside asm.  The
+// accumulators pass THROUGH the statement, so no instruction that reads them can be scheduled above it.
+__device__ __forceinline__ void mfma_drain(f32x4_t (&sa)[2], f32x4_t (&da)[2]) {
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sa[0]), "+v"(sa[1]), "+v"(da[0]), "+v"(da[1]));
+}
+
+// Scores phase of one 32-row streamed tile: sa[t] = A_tile[16t..][:] . Af (and da[t] = B_tile . Bf when TWO), the tile's
+// fragments read two 32-column slices (8 or 4 ds_read_b128) ahead of the MFMAs that use them.  `piece(c)` is called once per
+// slice pair, c = 0..7: the caller issues the next tile's DMA rows there, spread over the phase instead of in one burst.
+template <bool TWO, typename PIECE>
+__device__ __forceinline__ void scores_phase(const bf16* la, const bf16* lb, const bf16x8_t (&Af)[WNKS], const bf16x8_t (&Bf)[TWO ? WNKS : 1],
+                                             f32x4_t (&sa)[2], f32x4_t (&da)[2], int fr, int fg, PIECE&& piece) {
+    bf16x8_t fa[2][2][2], fb[2][2][2];                 // [register buffer][slice of the pair][16-row group]
+    auto rd = [&](int c, int buf) {
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int off = (16 * t + fr) * WP + (2 * c + kk) * 32 + fg * 8;
+                fa[buf][kk][t] = *reinterpret_cast<const bf16x8_t*>(&la[off]);
+                if (TWO) fb[buf][kk][t] = *reinterpret_cast<const bf16x8_t*>(&lb[off]);
+            }
+    };
+    rd(0, 0);
+#pragma unroll
+    for (int c = 0; c < WNKS / 2; c++) {
+        if (c + 1 < WNKS / 2) rd(c + 1, (c + 1) & 1);
+        piece(c);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                if (c == 0 && kk == 0) {
+                    mfma_v0(sa[t], fa[c & 1][kk][t], Af[2 * c + kk]);
+                    if (TWO) mfma_v0(da[t], fb[c & 1][kk][t], Bf[TWO ? 2 * c + kk : 0]);
+                } else {
+                    mfma_v(sa[t], fa[c & 1][kk][t], Af[2 * c + kk]);
+                    if (TWO) mfma_v(da[t], fb[c & 1][kk][t], Bf[TWO ? 2 * c + kk : 0]);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// Output phase: acc[n] += src_tile^T[16n.., 32 rows] . bfrag for the 32 column groups of the head, transposed fragments read
+// eight groups ahead.  `first8` holds the first eight, which the caller read before its vector work (tr_chunk).
+__device__ __forceinline__ void tr_chunk(const bf16* lsrc, int j, bf16x8_t (&ft)[8], int fg, int qq, int pp) {
+#pragma unroll
+    for (int n = 0; n < 8; n++) ft[n] = frag_tr(lsrc, WP, 0, 16 * (8 * j + n), fg, qq, pp);
+}
+__device__ __forceinline__ void output_phase(const bf16* lsrc, bf16x8_t (&ft0)[8], const bf16x8_t bfrag, f32x4_t (&acc)[WNDV], int fg, int qq, int pp) {
+    bf16x8_t ft1[8];
+#pragma unroll
+    for (int j = 0; j < WNDV / 8; j++) {
+        bf16x8_t (&cur)[8] = (j & 1) ? ft1 : ft0;
+        bf16x8_t (&nxt)[8] = (j & 1) ? ft0 : ft1;
+        if (j + 1 < WNDV / 8) tr_chunk(lsrc, j + 1, nxt, fg, qq, pp);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < 8; n++) mfma_out(acc[8 * j + n], cur[n], bfrag);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// one DMA row pair of the next tile (rows r = wave + 4c of both operands), c = 0..7
+__device__ __forceinline__ void stage_piece(const bf16* a, long lda, const bf16* b, long ldb, int row0, int S, unsigned lds0, int buf,
+                                            int wave, unsigned lane16, int c) {
+    const unsigned base = lds0 + (unsigned)(buf * 2 * WTILE * 2);
+    const int r = wave + 4 * c;
+    const int gr = min(row0 + r, S - 1);
+    dma_row(a + (long)gr * lda, base + (unsigned)(r * WP * 2), lane16);
+    dma_row(b + (long)gr * ldb, base + (unsigned)((WTILE + r * WP) * 2), lane16);
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -70,9 +167,9 @@ __global__ __launch_bounds__(256) void attn_fwd_w_k(const AttnP p) {
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = rb * 64, qw0 = q0 + wave * 16;
     const long head_off = (long)b * p.S * p.ld + (long)h * p.d;
-    const bf16* qg = (const bf16*)p.q + head_off;
-    const bf16* kg = (const bf16*)p.k + head_off;
-    const bf16* vg = (const bf16*)p.v + head_off;
+    const bf16* qg = uniform_ptr((const bf16*)p.q + head_off);       // scalar bases: the DMA row addresses are scalar arithmetic
+    const bf16* kg = uniform_ptr((const bf16*)p.k + head_off);
+    const bf16* vg = uniform_ptr((const bf16*)p.v + head_off);
     const int kend_blk = last_key(min(q0 + 63, p.S - 1), p.P, p.S) + 1;
     const int kend_w = qw0 < p.S ? last_key(min(qw0 + 15, p.S - 1), p.P, p.S) + 1 : 0;
     const int lim_w0 = qw0 < p.S ? last_key(qw0, p.P, p.S) : -1;
@@ -81,9 +178,9 @@ __global__ __launch_bounds__(256) void attn_fwd_w_k(const AttnP p) {
     stage_pair(kg, p.ld, vg, p.ld, 0, p.S, lds0, 0, wave, lane16);
     const int qi = qw0 + fr;
     const int lim = last_key(qi, p.P, p.S);
-    bf16x8_t qf[WNKS];
+    bf16x8_t qf[WNKS], none[1];
 #pragma unroll
-    for (int ks = 0; ks < WNKS; ks++) qf[ks] = frag_global(qg, p.ld, qi, ks * 32 + fg * 8, p.S, p.d);
+    for (int ks = 0; ks < WNKS; ks++) { qf[ks] = frag_global(qg, p.ld, qi, ks * 32 + fg * 8, p.S, p.d); pin_acc(qf[ks]); }
     f32x4_t oacc[WNDV];
 #pragma unroll
     for (int n = 0; n < WNDV; n++) oacc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -91,20 +188,17 @@ __global__ __launch_bounds__(256) void attn_fwd_w_k(const AttnP p) {
 
     for (int i = 0; i < ntiles; i++) {
         wait_tile();                                   // tile i landed; every wave is done with the other buffer
-        if (i + 1 < ntiles) stage_pair(kg, p.ld, vg, p.ld, (i + 1) * WT, p.S, lds0, (i + 1) & 1, wave, lane16);
+        const bool more = i + 1 < ntiles;
         const int k0 = i * WT;
         const bf16* lk = lds + (i & 1) * 2 * WTILE;
         const bf16* lv = lk + WTILE;
+        auto piece = [&](int c) { if (more) stage_piece(kg, p.ld, vg, p.ld, (i + 1) * WT, p.S, lds0, (i + 1) & 1, wave, lane16, c); };
         if (k0 < kend_w) {
-            f32x4_t sacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int ks = 0; ks < WNKS; ks++) {
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&lk[(16 * t + fr) * WP + ks * 32 + fg * 8]);
-                    sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sacc[t], 0, 0, 0);
-                }
-            }
+            f32x4_t sacc[2], unused[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+            scores_phase<false>(lk, lv, qf, none, sacc, unused, fr, fg, piece);
+            bf16x8_t ft0[8];
+            tr_chunk(lv, 0, ft0, fg, qq, pp);          // in flight under the drain and the vector work
+            mfma_drain(sacc, unused);
             const bool full = k0 + WT - 1 <= lim_w0;
             const int rel = lim - k0 - 4 * fg;
             float pv[8];
@@ -137,11 +231,10 @@ __global__ __launch_bounds__(256) void attn_fwd_w_k(const AttnP p) {
 #pragma unroll
             for (int e = 0; e < 8; e++) l_run += pv[e];
             const bf16x8_t pf = pack8(pv);
+            output_phase(lv, ft0, pf, oacc, fg, qq, pp);
+        } else {
 #pragma unroll
-            for (int n = 0; n < WNDV; n++) {
-                const bf16x8_t vf = frag_tr(lv, WP, 0, 16 * n, fg, qq, pp);
-                oacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[n], 0, 0, 0);
-            }
+            for (int c = 0; c < WT / 4; c++) piece(c);
         }
     }
     float l = l_run;
@@ -175,10 +268,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_w_k(const AttnP p) {
     const int b = bh / p.H, h = bh % p.H;
     const int q0 = rb * 64, qw0 = q0 + wave * 16;
     const long head_off = (long)b * p.S * p.ld + (long)h * p.d;
-    const bf16* qg = (const bf16*)p.q + head_off;
-    const bf16* kg = (const bf16*)p.k + head_off;
-    const bf16* vg = (const bf16*)p.v + head_off;
-    const bf16* dog = (const bf16*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d;
+    const bf16* qg = uniform_ptr((const bf16*)p.q + head_off);       // scalar bases: the DMA row addresses are scalar arithmetic
+    const bf16* kg = uniform_ptr((const bf16*)p.k + head_off);
+    const bf16* vg = uniform_ptr((const bf16*)p.v + head_off);
+    const bf16* dog = uniform_ptr((const bf16*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d);
     const int kend_blk = last_key(min(q0 + 63, p.S - 1), p.P, p.S) + 1;
     const int kend_w = qw0 < p.S ? last_key(min(qw0 + 15, p.S - 1), p.P, p.S) + 1 : 0;
     const int lim_w0 = qw0 < p.S ? last_key(qw0, p.P, p.S) : -1;
@@ -192,6 +285,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_w_k(const AttnP p) {
     for (int ks = 0; ks < WNKS; ks++) {
         qf[ks] = frag_global(qg, p.ld, qi, ks * 32 + fg * 8, p.S, p.d);
         gf[ks] = frag_global(dog, p.ld_o, qi, ks * 32 + fg * 8, p.S, p.d);
+        pin_acc(qf[ks]); pin_acc(gf[ks]);
     }
     float c0, c1;                                      // stablemax: 1/L and -delta/L;  softmax: lse and delta
     {
@@ -206,24 +300,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_w_k(const AttnP p) {
 
     for (int i = 0; i < ntiles; i++) {
         wait_tile();
-        if (i + 1 < ntiles) stage_pair(kg, p.ld, vg, p.ld, (i + 1) * WT, p.S, lds0, (i + 1) & 1, wave, lane16);
+        const bool more = i + 1 < ntiles;
         const int k0 = i * WT;
         const bf16* lk = lds + (i & 1) * 2 * WTILE;
         const bf16* lv = lk + WTILE;
+        auto piece = [&](int c) { if (more) stage_piece(kg, p.ld, vg, p.ld, (i + 1) * WT, p.S, lds0, (i + 1) & 1, wave, lane16, c); };
         if (k0 < kend_w) {
-            f32x4_t sa[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-            f32x4_t da[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int ks = 0; ks < WNKS; ks++) {
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    const int off = (16 * t + fr) * WP + ks * 32 + fg * 8;
-                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&lk[off]);
-                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(&lv[off]);
-                    sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sa[t], 0, 0, 0);
-                    da[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[ks], da[t], 0, 0, 0);
-                }
-            }
+            f32x4_t sa[2], da[2];
+            scores_phase<true>(lk, lv, qf, gf, sa, da, fr, fg, piece);
+            bf16x8_t ft0[8];
+            tr_chunk(lk, 0, ft0, fg, qq, pp);          // in flight under the drain and the vector work
+            mfma_drain(sa, da);
             const bool full = k0 + WT - 1 <= lim_w0;
             const int rel = lim - k0 - 4 * fg;
             float e8[8];
@@ -241,11 +328,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_w_k(const AttnP p) {
                 e8[e] = (full || 16 * t + r <= rel) ? ds : 0.f;
             }
             const bf16x8_t dsf = pack8(e8);
+            output_phase(lk, ft0, dsf, dqa, fg, qq, pp);
+        } else {
 #pragma unroll
-            for (int n = 0; n < WNDV; n++) {
-                const bf16x8_t kt = frag_tr(lk, WP, 0, 16 * n, fg, qq, pp);
-                dqa[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf, dqa[n], 0, 0, 0);
-            }
+            for (int c = 0; c < WT / 4; c++) piece(c);
         }
     }
     if (qi < p.S) {
@@ -281,10 +367,10 @@ __device__ __forceinline__ void attn_bwd_dkv_w_body(const AttnP& p, char* smem) 
     const int b = bh / p.H, h = bh % p.H;
     const int kb0 = rb * 64, kw0 = kb0 + wave * 16;
     const long head_off = (long)b * p.S * p.ld + (long)h * p.d;
-    const bf16* qg = (const bf16*)p.q + head_off;
-    const bf16* kg = (const bf16*)p.k + head_off;
-    const bf16* vg = (const bf16*)p.v + head_off;
-    const bf16* dog = (const bf16*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d;
+    const bf16* qg = uniform_ptr((const bf16*)p.q + head_off);       // scalar bases: the DMA row addresses are scalar arithmetic
+    const bf16* kg = uniform_ptr((const bf16*)p.k + head_off);
+    const bf16* vg = uniform_ptr((const bf16*)p.v + head_off);
+    const bf16* dog = uniform_ptr((const bf16*)p.dO + (long)b * p.S * p.ld_o + (long)h * p.d);
     const long statbase = ((long)b * p.H + h) * p.S;
     const int qstart_blk = (first_query(kb0, p.P) / WT) * WT;
     const int qstart_w = first_query(kw0, p.P);                               // first query that sees any key of this wave
@@ -308,7 +394,8 @@ __device__ __forceinline__ void attn_bwd_dkv_w_body(const AttnP& p, char* smem) 
 #pragma unroll
     for (int ks = 0; ks < WNKS; ks++) {
         kf[ks] = frag_global(kg, p.ld, kj, ks * 32 + fg * 8, p.S, p.d);
-        if (ROLE_DK) vf[ks] = frag_global(vg, p.ld, kj, ks * 32 + fg * 8, p.S, p.d);
+        pin_acc(kf[ks]);
+        if (ROLE_DK) { vf[ks] = frag_global(vg, p.ld, kj, ks * 32 + fg * 8, p.S, p.d); pin_acc(vf[ks]); }
     }
     f32x4_t acc[WNDV];
 #pragma unroll
@@ -316,26 +403,20 @@ __device__ __forceinline__ void attn_bwd_dkv_w_body(const AttnP& p, char* smem) 
 
     for (int i = 0; i < ntiles; i++) {
         wait_tile();                                   // (the first one also publishes lstat)
-        if (i + 1 < ntiles) stage_pair(qg, p.ld, dog, p.ld_o, qstart_blk + (i + 1) * WT, p.S, lds0, (i + 1) & 1, wave, lane16);
+        const bool more = i + 1 < ntiles;
         const int q0 = qstart_blk + i * WT;
         const bf16* lq = lds + (i & 1) * 2 * WTILE;
         const bf16* lg = lq + WTILE;
+        auto piece = [&](int c) {
+            if (more) stage_piece(qg, p.ld, dog, p.ld_o, qstart_blk + (i + 1) * WT, p.S, lds0, (i + 1) & 1, wave, lane16, c);
+        };
         if (wave_live && q0 + WT > qstart_w) {
-            f32x4_t sa[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-            f32x4_t da[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int ks = 0; ks < WNKS; ks++) {
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    const int off = (16 * t + fr) * WP + ks * 32 + fg * 8;
-                    const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(&lq[off]);
-                    sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], sa[t], 0, 0, 0);
-                    if (ROLE_DK) {
-                        const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(&lg[off]);
-                        da[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf[ks], da[t], 0, 0, 0);
-                    }
-                }
-            }
+            f32x4_t sa[2], da[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+            scores_phase<ROLE_DK>(lq, lg, kf, vf, sa, da, fr, fg, piece);
+            const bf16* lsrc = ROLE_DK ? lq : lg;
+            bf16x8_t ft0[8];
+            tr_chunk(lsrc, 0, ft0, fg, qq, pp);        // in flight under the drain and the vector work
+            mfma_drain(sa, da);
             const bool full = q0 >= qfull_w;                   // wave-uniform
             const int rel = qmin - q0 - 4 * fg;                // query 16t + r of this lane sees the key iff 16t + r >= rel
             float e8[8];
@@ -363,12 +444,10 @@ __device__ __forceinline__ void attn_bwd_dkv_w_body(const AttnP& p, char* smem) 
                 }
             }
             const bf16x8_t bf = pack8(e8);                     // P (dV role) or dS (dK role), queries on the k axis
-            const bf16* lsrc = ROLE_DK ? lq : lg;
+            output_phase(lsrc, ft0, bf, acc, fg, qq, pp);
+        } else {
 #pragma unroll
-            for (int n = 0; n < WNDV; n++) {
-                const bf16x8_t at = frag_tr(lsrc, WP, 0, 16 * n, fg, qq, pp);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at, bf, acc[n], 0, 0, 0);
-            }
+            for (int c = 0; c < WT / 4; c++) piece(c);
         }
     }
     if (kj < p.S) {
