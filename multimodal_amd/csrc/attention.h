@@ -22,3 +22,9 @@ int attn_fast_bwd(const AttnP& p, int mode, hipStream_t st);      // dq and dk/d
 bool attn_wide_ok(const AttnP& p);
 int attn_wide_fwd(const AttnP& p, int mode, hipStream_t st);
 int attn_wide_bwd(const AttnP& p, int mode, hipStream_t st);      // dq and dk/dv kernels (delta already computed)
+
+// bf16 forms with a whole head's streamed operands resident in LDS (attention_res.hip): head_dim <= 128 and S small enough
+// (S = 315 at d = 100, S = 238 at d = 128), one workgroup per (batch, head), no barrier after the load.
+bool attn_res_ok(const AttnP& p);
+int attn_res_fwd(const AttnP& p, int mode, hipStream_t st);
+int attn_res_bwd(const AttnP& p, int mode, hipStream_t st);       // dq and dk/dv kernels (delta already computed)

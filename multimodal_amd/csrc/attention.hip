@@ -537,7 +537,9 @@ extern "C" int mm_prefix_attn_fwd(const void* q, const void* k, const void* v, v
     static const bool force_generic = getenv("MM_ATTN_GENERIC") != nullptr;     // A/B switch for debugging
     static const bool force_v2 = getenv("MM_ATTN_V2") != nullptr;               // A/B switch: the previous fast generation
     static const bool no_wide = getenv("MM_ATTN_NO_WIDE") != nullptr;           // A/B switch: head_dim 512 on the staged kernels
+    static const bool no_res = getenv("MM_ATTN_NO_RES") != nullptr;             // A/B switch: tiled kernels instead of the resident ones
     if (!force_generic && dtype == MM_BF16 && rot == 0 && p.vec_ok && ((uintptr_t)o) % 8 == 0) {
+        if (!force_v2 && !no_res && attn_res_ok(p)) return attn_res_fwd(p, mode, st);        // whole head resident in LDS
         if (!force_v2 && attn_fast_ok(p)) return attn_fast_fwd(p, mode, st);
         if (!force_v2 && !no_wide && attn_wide_ok(p)) return attn_wide_fwd(p, mode, st);     // head_dim 512
         return fwd2_dispatch(p, mode, st);
@@ -1507,16 +1509,20 @@ extern "C" int mm_prefix_attn_bwd(const void* q, const void* k, const void* v, c
     p.B = (int)B; p.H = (int)H; p.S = (int)S; p.d = (int)d; p.rot = (int)rot; p.P = (int)prompt_len;
     p.ld = ld_qkv; p.ld_o = H * d; p.ld_d = ld_dqkv; p.scale = (float)(1.0 / sqrt((double)d));
     p.vec_ok = attn_vec_ok(q, k, v, ld_qkv, d, dtype) && attn_vec_ok(d_o, d_o, d_o, H * d, d, dtype);
+    static const bool force_generic = getenv("MM_ATTN_GENERIC") != nullptr;     // A/B switch for debugging
+    const bool al8 = (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8) == 0 && ld_dqkv % 4 == 0;
+    // measured: the fast form wins up to d = 192 (1.05-1.5x); beyond that its register footprint loses to the staged kernels
+    static const bool force_v2 = getenv("MM_ATTN_V2") != nullptr;               // A/B switch: the previous fast generation
+    static const bool no_res = getenv("MM_ATTN_NO_RES") != nullptr;             // A/B switch: tiled kernels instead of the resident ones
+    const bool fast = !force_generic && dtype == MM_BF16 && rot == 0 && p.vec_ok && al8 && d <= 192;
+    // whole head resident in LDS; its dQ kernel computes delta = rowsum(dO * O) itself (8-byte aligned o / dO rows)
+    if (fast && !force_v2 && !no_res && attn_res_ok(p) && (((uintptr_t)o | (uintptr_t)d_o) % 8) == 0) return attn_res_bwd(p, mode, st);
     const long rows = B * S * H;
     hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)cdiv(rows, 16)), dim3(256), 0, st, o, d_o, (float*)workspace, rows, (int)H, (int)S,
                        (int)d, (long)(H * d), (long)(H * d),
                        dtype == MM_BF16 ? ((d % 4 == 0 && (((uintptr_t)o | (uintptr_t)d_o) % 8) == 0) ? 2 : 1) : 0);
     MM_LAUNCH_CHECK();
-    static const bool force_generic = getenv("MM_ATTN_GENERIC") != nullptr;     // A/B switch for debugging
-    const bool al8 = (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8) == 0 && ld_dqkv % 4 == 0;
-    // measured: the fast form wins up to d = 192 (1.05-1.5x); beyond that its register footprint loses to the staged kernels
-    static const bool force_v2 = getenv("MM_ATTN_V2") != nullptr;               // A/B switch: the previous fast generation
-    if (!force_generic && dtype == MM_BF16 && rot == 0 && p.vec_ok && al8 && d <= 192) {
+    if (fast) {
         if (!force_v2 && attn_fast_ok(p)) return attn_fast_bwd(p, mode, st);
         return bwd_dispatch5(p, mode, st);
     }

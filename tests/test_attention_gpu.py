@@ -31,6 +31,11 @@ CASES = [  # B, H, d, S, P
     # head_dim 512 (attention_wide.hip on the pre-rotated bf16 path): the real_config_mup sequence, a causal-only head,
     # lengths that are / are not multiples of the 32-row tiles and of the 64-row workgroup blocks
     (1, 2, 512, 315, 221), (2, 1, 512, 130, 0), (1, 1, 512, 64, 64), (1, 3, 512, 97, 33),
+    # >= 128 heads and a head that fits LDS: the whole-head-resident kernels (attention_res.hip) on the pre-rotated bf16 path --
+    # the local/real_config head (d 100: three 32-column steps + one of 16, 7 output tiles), the nocat head (d 128, softmax in
+    # its config), narrower geometries, causal-only and prompt-only masks, lengths off the 16- and 32-row grids
+    (8, 16, 100, 315, 221), (16, 8, 128, 238, 159), (4, 32, 32, 70, 40), (2, 64, 64, 97, 33), (4, 32, 96, 80, 0),
+    (2, 64, 112, 130, 130), (8, 16, 100, 64, 3),
 ]
 
 
