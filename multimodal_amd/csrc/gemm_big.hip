@@ -345,513 +345,8 @@ __global__ __launch_bounds__(128 * WN, 1) void gemm_big_k(const GemmP p) {
     }
 }
 
-#ifdef GEMM_LAB   // experimental main loops, measured in benchmarks/gemm_lab.hip and not faster on the decoder shapes
-// ------------------------------------------------------------------------------------------------
-// Software-pipelined form of gemm_big_k (same tile, LDS image, DMA staging, epilogue and contract).  What the cycle stamps of
-// gemm_big_k showed (benchmarks/gemm_lab.hip, 256x256 tile, operands cache-resident): a K step takes 3500 cycles against
-// 2048 of MFMA work because each wave alternates between phases that feed the matrix pipe and phases that cannot (12 fragment
-// reads with their latency exposed, 8 DMA pieces at 60-190 cycles of issue each, the landing wait, the barrier), and two waves
-// a SIMD only hide each other's gaps while they are out of phase.  Here every wave keeps MFMAs issued all the time:
-//   * a half step's fragments are read while the PREVIOUS half step is multiplied: after the MFMAs of row i its A fragment
-//     register is refilled with row i of the next half step (needed TM rows later), the B fragments have two register sets;
-//   * the fragments of a tile's second half are held across the barrier, so the first thing after a barrier is 32-35 MFMAs
-//     from registers, under which the fragments of the tile that just landed arrive and the DMA pieces of the tile after it
-//     go out one per row of MFMAs;
-//   * one barrier per K tile; the pieces have the whole second half step to land before it.
-// ------------------------------------------------------------------------------------------------
-template <typename TO, int TM, int TN, int WN>
-__global__ __launch_bounds__(128 * WN, 1) void gemm_pipe_k(const GemmP p) {
-    typedef BigTile<TM, TN, WN> G;
-    constexpr int BM = G::BM, BN = G::BN;
-    static_assert(TN <= TM && G::PPW <= 2 * TM, "prefetch / piece slots per row");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / WN, wc = wave % WN;
-    const int kt0 = p.partial ? blockIdx.y * (p.k_per_split / BK) : 0;
-    const int nk = p.partial ? min(p.K / BK - kt0, p.k_per_split / BK) : p.K / BK;
-    const int nwg = p.tiles_m * p.tiles_n;
-    long m0, n0;
-    {
-        const int id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
-        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-        m0 = (long)(wg / p.tiles_n) * BM; n0 = (long)(wg % p.tiles_n) * BN;
-    }
-    const int fr = lane & 15, fg = lane >> 4;
-    int offA[2], offB[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-        const int slot = ((ks * 4 + fg) ^ (fr >> 1)) << 4;
-        offA[ks] = (wr * (BM / 2) + fr) * 128 + slot;
-        offB[ks] = (BM + wc * (BN / WN) + fr) * 128 + slot;
-    }
-    // DMA sources: scalar base (A or B: a piece never straddles) + 32-bit lane offset (host: M * lda and N * ldb below 4 GiB)
-    const char* const baseA = (const char*)p.A + (long)kt0 * BK * 2;
-    const char* const baseB = (const char*)p.B + (long)kt0 * BK * 2;
-    unsigned voff[G::PPW];
-#pragma unroll
-    for (int i = 0; i < G::PPW; i++) {
-        const int q = wave + G::NW * i;
-        const bool isA = q * 8 < BM;                                       // wave-uniform
-        const int lrow = q * 8 + (lane >> 3) - (isA ? 0 : BM);
-        const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);
-        long gr = (isA ? m0 : n0) + lrow;
-        const long lim = (isA ? p.M : p.N) - 1;
-        if (gr > lim) gr = lim;
-        voff[i] = (unsigned)(gr * (isA ? p.lda : p.ldb) * 2 + chunk * 16);
-    }
-    unsigned char* nbase = smem;                                           // where and from where the next tile's pieces go
-    const char *nA = baseA, *nB = baseB;                                   // kept in SGPRs: the address is scalar base + lane offset
-    auto uniform = [](const char* q) {
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)q), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)q >> 32));
-        return (const char*)(((uintptr_t)hi << 32) | lo);
-    };
-    auto set_next = [&](long noff) { nA = uniform(baseA + noff); nB = uniform(baseB + noff); };
-    bool more = false;
-    auto piece = [&](int i) {
-        if (i < G::PPW && more && wave + G::NW * i < G::PIECES)
-            __builtin_amdgcn_global_load_lds((glb_vp)(((wave + G::NW * i) * 8 < BM ? nA : nB) + voff[i]), (lds_vp)(nbase + (wave + G::NW * i) * 1024), 16, 0, 0);
-    };
-    f32x4_t acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t fa[TM], fb[2][TN];
-    // one half step: MFMAs of the held fragments (set SET of fb), row by row; behind row i: refill fa[i] and fb[SET^1][i] from
-    // (ls, ks) and issue DMA piece(s)
-#define PIPE_PHASE(SET, MMA, PF, ls, ks, PIECES_ON)                                                                      \
-    _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                     \
-        if (MMA) {                                                                                                       \
-            _Pragma("unroll") for (int j = 0; j < TN; j++)                                                               \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[SET][j], fa[i], acc[i][j], 0, 0, 0);             \
-        }                                                                                                                \
-        if (PF) {                                                                                                        \
-            fa[i] = *reinterpret_cast<const bf16x8_t*>((ls) + offA[ks] + i * 2048);                                      \
-            if (i < TN) fb[(SET) ^ 1][i] = *reinterpret_cast<const bf16x8_t*>((ls) + offB[ks] + i * 2048);               \
-        }                                                                                                                \
-        if (PIECES_ON) { piece(i); if (TM + i < G::PPW) piece(TM + i); }                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-    }
-    constexpr int LAB_BASE = G::LDS_BYTES;
-    more = nk > 0;
-    // ---- prologue: tile 0 (and 1) requested in a burst; first half of tile 0 read with its latency exposed (once per tile)
-#pragma unroll
-    for (int i = 0; i < G::PPW; i++) piece(i);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    more = nk > 1; nbase = smem + G::STAGE_BYTES; set_next(BK * 2);
-    if (nk > 0) {
-        PIPE_PHASE(1, false, true, smem, 0, true)
-        PIPE_PHASE(0, true, true, smem, 1, false)
-    }
-    // ---- steady state: no branch except the scalar ones around single DMA pieces
-    for (int kt = 1; kt < nk; kt++) {
-        STAMP(kt, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        STAMP(kt, 1);
-        __syncthreads();                                                   // tile kt landed; everyone has read tile kt-1
-        STAMP(kt, 2);
-        const unsigned char* ls = smem + (kt & 1) * G::STAGE_BYTES;
-        more = kt + 1 < nk; nbase = smem + ((kt + 1) & 1) * G::STAGE_BYTES; set_next((long)(kt + 1) * BK * 2);
-        PIPE_PHASE(1, true, true, ls, 0, true)                             // second half of tile kt-1 from registers
-        STAMP(kt, 3);
-        PIPE_PHASE(0, true, true, ls, 1, false)                            // first half of tile kt
-        STAMP(kt, 4);
-    }
-    if (nk > 0) { PIPE_PHASE(1, true, false, smem, 0, false) }             // second half of the last tile
-#undef PIPE_PHASE
-    STAMP_DUMP();
-    __syncthreads();
-    big_epilogue<TO, TM, TN, G::EPI_ROW>(p, acc, smem + G::STAGE_BYTES + wave * G::EPI_WAVE, m0 + wr * (BM / 2), n0 + wc * (BN / WN), lane);
-}
-
-// ------------------------------------------------------------------------------------------------
-// gemm_pipe_k with the DMA spread evenly: two LDS stages for A and THREE for B (2 x 32 KB + 3 x 32 KB = 160 KB at 256 x 256).
-// A(k+1) goes out under the first half step of step k, B(k+2) under the second: one piece per 8 MFMAs of a wave all the
-// time (the pattern benchmarks/dma_issue.hip runs at 1.6 PF/s), every piece has at least half a step to land, and the wait
-// before the barrier is a counted one (the B pieces just issued stay in flight).
-// ------------------------------------------------------------------------------------------------
-template <int N> __device__ __forceinline__ void vm_wait();
-template <typename TO, int TM, int TN, int WN>
-__global__ __launch_bounds__(128 * WN, 1) void gemm_pipe3_k(const GemmP p) {
-    typedef BigTile<TM, TN, WN> G;
-    constexpr int BM = G::BM, BN = G::BN, ASZ = BM * 128, BSZ = BN * 128, CA = (BM / 8 + G::NW - 1) / G::NW, CB = BN / 8 / G::NW;
-    static_assert(WN == 4 && TN <= TM && 2 * CA - 1 <= TM && 2 * CB - 1 <= TM && CB * G::NW * 8 == BN, "piece slots per row");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    unsigned char* const smemB = smem + 2 * ASZ;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / WN, wc = wave % WN;
-    const int kt0 = p.partial ? blockIdx.y * (p.k_per_split / BK) : 0;
-    const int nk = p.partial ? min(p.K / BK - kt0, p.k_per_split / BK) : p.K / BK;
-    const int nwg = p.tiles_m * p.tiles_n;
-    long m0, n0;
-    {
-        const int id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
-        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-        m0 = (long)(wg / p.tiles_n) * BM; n0 = (long)(wg % p.tiles_n) * BN;
-    }
-    const int fr = lane & 15, fg = lane >> 4;
-    int offA[2], offB[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-        const int slot = ((ks * 4 + fg) ^ (fr >> 1)) << 4;
-        offA[ks] = (wr * (BM / 2) + fr) * 128 + slot;
-        offB[ks] = (wc * (BN / WN) + fr) * 128 + slot;
-    }
-    const char* const baseA = (const char*)p.A + (long)kt0 * BK * 2;
-    const char* const baseB = (const char*)p.B + (long)kt0 * BK * 2;
-    unsigned voffA[CA], voffB[CB];
-#pragma unroll
-    for (int i = 0; i < CA; i++) {
-        const int lrow = (wave + G::NW * i) * 8 + (lane >> 3);
-        long gr = m0 + lrow; if (gr > p.M - 1) gr = p.M - 1;
-        voffA[i] = (unsigned)(gr * p.lda * 2 + (((lane & 7) ^ ((lrow >> 1) & 7)) << 4));
-    }
-#pragma unroll
-    for (int i = 0; i < CB; i++) {
-        const int lrow = (wave + G::NW * i) * 8 + (lane >> 3);
-        long gr = n0 + lrow; if (gr > p.N - 1) gr = p.N - 1;
-        voffB[i] = (unsigned)(gr * p.ldb * 2 + (((lane & 7) ^ ((lrow >> 1) & 7)) << 4));
-    }
-    auto uniform = [](const char* q) {
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)q), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)q >> 32));
-        return (const char*)(((uintptr_t)hi << 32) | lo);
-    };
-    const char *nA = baseA, *nB = baseB;                                   // scalar sources of the pieces being issued
-    unsigned char *dA = smem, *dB = smemB;                                 // their LDS stages
-    bool onA = false, onB = false;
-    auto pieceA = [&](int i) {
-        if (i < CA && onA && (wave + G::NW * i) * 8 < BM)
-            __builtin_amdgcn_global_load_lds((glb_vp)(nA + voffA[i]), (lds_vp)(dA + (wave + G::NW * i) * 1024), 16, 0, 0);
-    };
-    auto pieceB = [&](int i) {
-        if (i < CB && onB)
-            __builtin_amdgcn_global_load_lds((glb_vp)(nB + voffB[i]), (lds_vp)(dB + (wave + G::NW * i) * 1024), 16, 0, 0);
-    };
-    f32x4_t acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t fa[TM], fb[2][TN];
-    // PC: 0 no pieces, 1 A pieces, 2 B pieces -- piece c goes out behind row 2c
-#define PIPE3_PHASE(SET, MMA, PF, lsA, lsB, ks, PC)                                                                      \
-    _Pragma("unroll") for (int i = 0; i < TM; i++) {                                                                     \
-        if (MMA) {                                                                                                       \
-            _Pragma("unroll") for (int j = 0; j < TN; j++)                                                               \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[SET][j], fa[i], acc[i][j], 0, 0, 0);             \
-        }                                                                                                                \
-        if (PF) {                                                                                                        \
-            fa[i] = *reinterpret_cast<const bf16x8_t*>((lsA) + offA[ks] + i * 2048);                                     \
-            if (i < TN) fb[(SET) ^ 1][i] = *reinterpret_cast<const bf16x8_t*>((lsB) + offB[ks] + i * 2048);              \
-        }                                                                                                                \
-        if ((PC) == 1 && (i & 1) == 0) pieceA(i >> 1);                                                                   \
-        if ((PC) == 2 && (i & 1) == 0) pieceB(i >> 1);                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-    }
-    constexpr int LAB_BASE = 2 * ASZ + 3 * BSZ;
-    auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    // ---- prologue: A(0), B(0), B(1) in a burst
-    onA = onB = nk > 0; nA = uniform(baseA); nB = uniform(baseB); dA = smem; dB = smemB;
-#pragma unroll
-    for (int i = 0; i < CA; i++) pieceA(i);
-#pragma unroll
-    for (int i = 0; i < CB; i++) pieceB(i);
-    onB = nk > 1; nB = uniform(baseB + BK * 2); dB = smemB + BSZ;
-#pragma unroll
-    for (int i = 0; i < CB; i++) pieceB(i);
-    int bcur = 0;                                                          // B stage of tile kt; tile kt + 2 goes to (bcur + 2) % 3
-    for (int kt = 0; kt < nk; kt++) {
-        STAMP(kt, 0);
-        if (kt + 1 < nk) vm_wait<CB>(); else vm_wait<0>();                 // all but the B pieces issued last have landed
-        STAMP(kt, 1);
-        barrier();                                                         // A(kt), B(kt) visible; everyone has read tile kt-1
-        STAMP(kt, 2);
-        const unsigned char* lsA = smem + (kt & 1) * ASZ;
-        const unsigned char* lsB = smemB + bcur * BSZ;
-        const int b2 = bcur == 0 ? 2 : bcur - 1;                           // (bcur + 2) % 3
-        onA = kt + 1 < nk; nA = uniform(baseA + (long)(kt + 1) * BK * 2); dA = smem + ((kt + 1) & 1) * ASZ;
-        onB = kt + 2 < nk; nB = uniform(baseB + (long)(kt + 2) * BK * 2); dB = smemB + b2 * BSZ;
-        if (kt > 0) { PIPE3_PHASE(1, true, true, lsA, lsB, 0, 1) }         // second half of tile kt-1 from registers; A(kt+1) out
-        else { PIPE3_PHASE(1, false, true, lsA, lsB, 0, 1) }
-        STAMP(kt, 3);
-        PIPE3_PHASE(0, true, true, lsA, lsB, 1, 2)                         // first half of tile kt; B(kt+2) out
-        STAMP(kt, 4);
-        bcur = bcur == 2 ? 0 : bcur + 1;
-    }
-    if (nk > 0) { PIPE3_PHASE(1, true, false, smem, smemB, 0, 0) }         // second half of the last tile
-#undef PIPE3_PHASE
-    STAMP_DUMP();
-    __syncthreads();
-    big_epilogue<TO, TM, TN, G::EPI_ROW>(p, acc, smem + wave * G::EPI_WAVE, m0 + wr * (BM / 2), n0 + wc * (BN / WN), lane);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Ring form of gemm_big_k (same tile, waves, epilogue and contract).  Why: with two 64-deep stages the loads of step k+1 are
-// issued at the start of step k and must have landed one step later -- 70 KB in flight per CU against a loaded memory
-// latency of about 2 us: the step took the latency (1.6-2.1 us measured on every shape), not its MFMA time (1.0 us).  Here
-// the K loop moves 32 columns a stage through a ring of NS stages (4 for the 224x320 tile): NS-1 stages (104 KB) are in flight
-// while one is multiplied, every wave waits with a COUNTED vmcnt for its own pieces of the oldest stage only, and one barrier
-// per stage publishes them and hands the stage read last back to the DMA.
-//   * LDS image of a stage: rows of 64 bytes (4 chunks of 16), chunk c of row r in slot c ^ g[(r>>2)&3], g = {0,2,3,1}: the
-//     16 lanes served together by a ds_read_b128 hold 16 different rows, 8 of chunk c and 8 of chunk c^1, and land in 16
-//     different 16-byte slots of the 256-byte bank row (4 rows x 4 slots) -> conflict-free;
-//   * the two waves of a SIMD run one stage apart as in gemm_big_k (the late one multiplies stage h-1 while the early one reads
-//     stage h), so fragment reads sit under the partner's MFMAs.
-// ------------------------------------------------------------------------------------------------
-constexpr int RK = 32;                                                 // K columns per ring stage
-template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// wait until at most `ahead` later stages of this wave's DMA pieces (C or C + 1 a stage) are still in flight
-template <int A, int C> __device__ __forceinline__ void vm_wait_stages(int ahead, bool big) {
-    if (ahead >= A) { if (big) vm_wait<A * (C + 1)>(); else vm_wait<A * C>(); }
-    else if constexpr (A > 0) vm_wait_stages<A - 1, C>(ahead, big);
-}
-__device__ __forceinline__ int ring_swz(int row) { return (0x1320 >> (((row >> 2) & 3) << 2)) & 3; }
-
-template <int TM, int TN, int WN> struct RingTile {
-    typedef BigTile<TM, TN, WN> G;
-    static constexpr int STAGE = (G::BM + G::BN) * RK * 2;
-    static constexpr int NS = (163840 - LAB_LDS) / STAGE < 6 ? (163840 - LAB_LDS) / STAGE : 6;
-    static constexpr int LDS_BYTES = NS * STAGE;
-    static constexpr int PIECES = (G::BM + G::BN) / 16;                // 1 KiB pieces (16 rows of 64 bytes)
-    static constexpr int CLO = PIECES / G::NW, EXTRA = PIECES % G::NW, PPW = CLO + (EXTRA ? 1 : 0);
-    static_assert(NS >= 3 && G::BM % 16 == 0 && G::BN % 16 == 0 && 8 * G::EPI_WAVE <= LDS_BYTES, "ring tile");
-};
-
-template <typename TO, int TM, int TN, int WN>
-__global__ __launch_bounds__(128 * WN, 1) void gemm_ring_k(const GemmP p) {
-    typedef BigTile<TM, TN, WN> G;
-    typedef RingTile<TM, TN, WN> R;
-    constexpr int BM = G::BM, BN = G::BN, NS = R::NS;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / WN, wc = wave % WN;
-    const int kt0 = p.partial ? blockIdx.y * (p.k_per_split / BK) : 0;
-    const int nh = 2 * (p.partial ? min(p.K / BK - kt0, p.k_per_split / BK) : p.K / BK);      // ring stages of this workgroup
-    const int nwg = p.tiles_m * p.tiles_n;
-    long m0, n0;
-    {
-        const int id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
-        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-        m0 = (long)(wg / p.tiles_n) * BM; n0 = (long)(wg % p.tiles_n) * BN;
-    }
-    // ---- fragment read offsets (bytes inside a stage); a wave's first row is a multiple of 16, so the swizzle depends on fr only
-    const int fr = lane & 15, fg = lane >> 4;
-    const int fslot = (fg ^ ring_swz(fr)) << 4;
-    const int offA = (wr * (BM / 2) + fr) * 64 + fslot, offB = (BM + wc * (BN / WN) + fr) * 64 + fslot;
-    // ---- staging: piece q = wave + NW*i covers rows 16q .. 16q+15 of the stacked [A rows ; B rows] image
-    const bf16* src[R::PPW];
-#pragma unroll
-    for (int i = 0; i < R::PPW; i++) {
-        const int q = wave + G::NW * i;
-        const int row = q * 16 + (lane >> 2);
-        const bool isA = row < BM;
-        const int lrow = isA ? row : row - BM;
-        const int chunk = (lane & 3) ^ ring_swz(lrow);
-        long gr = (isA ? m0 : n0) + lrow;
-        const long lim = (isA ? p.M : p.N) - 1;
-        if (gr > lim) gr = lim;
-        src[i] = (isA ? (const bf16*)p.A + gr * p.lda : (const bf16*)p.B + gr * p.ldb) + chunk * 8 + (long)kt0 * BK;
-    }
-    const bool big = wave < R::EXTRA;                                      // this wave moves CLO + 1 pieces a stage
-    auto stage = [&](int h, int buf) {
-        unsigned char* base = smem + buf * R::STAGE;
-#pragma unroll
-        for (int i = 0; i < R::CLO; i++)
-            __builtin_amdgcn_global_load_lds((glb_vp)(src[i] + (long)h * RK), (lds_vp)(base + (wave + G::NW * i) * 1024), 16, 0, 0);
-        if constexpr (R::EXTRA > 0)
-            if (big) __builtin_amdgcn_global_load_lds((glb_vp)(src[R::CLO] + (long)h * RK), (lds_vp)(base + (wave + G::NW * R::CLO) * 1024), 16, 0, 0);
-    };
-    // plain s_barrier: __syncthreads() carries a workgroup release fence, i.e. vmcnt(0) -- it would drain the ring
-    auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
-#pragma unroll
-    for (int s = 0; s < NS - 1; s++)
-        if (s < nh) stage(s, s);
-
-    f32x4_t acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t fa[TM], fb[TN];
-    auto rd = [&](const unsigned char* ls) {
-#pragma unroll
-        for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const bf16x8_t*>(ls + offB + j * 1024);
-#pragma unroll
-        for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const bf16x8_t*>(ls + offA + i * 1024);
-    };
-    auto mm = [&]() {
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    };
-    const bool late = p.stagger && wave >= G::NW / 2;                      // scalar
-    int buf = 0, nbuf = NS - 1;                                            // stage h lives in buf; stage h + NS - 1 goes to nbuf
-    constexpr int LAB_BASE = R::LDS_BYTES;
-    if (!late) {
-        for (int h = 0; h < nh; h++) {
-            STAMP(h, 0);
-            vm_wait_stages<NS - 2, R::CLO>(nh - 1 - h, big);               // own pieces of stage h landed
-            STAMP(h, 1);
-            barrier();                                                     // everyone's did; everyone is done with stage h-1
-            STAMP(h, 2);
-            if (h + NS - 1 < nh) stage(h + NS - 1, nbuf);
-            STAMP(h, 3);
-            rd(smem + buf * R::STAGE); mm();
-            STAMP(h, 4);
-            buf = buf + 1 == NS ? 0 : buf + 1; nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
-        }
-    } else {
-        for (int h = 0; h < nh; h++) {
-            STAMP(h, 0);
-            vm_wait_stages<NS - 2, R::CLO>(nh - 1 - h, big);
-            STAMP(h, 1);
-            barrier();
-            STAMP(h, 2);
-            if (h > 0) mm();                                               // stage h-1 (fragments held in registers)
-            STAMP(h, 3);
-            // a DMA piece costs its wave 60-190 cycles of issue: the late wave issues its pieces AFTER its MFMAs, i.e. under the
-            // early wave's (which issued its own under these), not both right after the barrier with the matrix pipe idle
-            if (h + NS - 1 < nh) stage(h + NS - 1, nbuf);
-            STAMP(h, 4);
-            rd(smem + buf * R::STAGE);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // in registers before the stage is handed back
-            STAMP(h, 5);
-            buf = buf + 1 == NS ? 0 : buf + 1; nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
-        }
-        if (nh > 0) mm();
-    }
-    STAMP_DUMP();
-    __syncthreads();                                                       // every wave is done with the operand stages
-    big_epilogue<TO, TM, TN, G::EPI_ROW>(p, acc, smem + wave * G::EPI_WAVE, m0 + wr * (BM / 2), n0 + wc * (BN / WN), lane);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Register-staged form of gemm_big_k (same tile, LDS image, waves, stagger, epilogue and contract).  Why: cycle stamps of the
-// DMA kernels (benchmarks/gemm_lab.hip) show that issuing a wave's 8-9 global_load_lds pieces of a K step costs that wave
-// 600-800 cycles (the instruction waits for the address/texture path; nothing else of the wave issues meanwhile), a third of a
-// step's MFMA time, and leaves the two waves of a SIMD out of balance.  A plain global_load_dwordx4 issues in a few cycles:
-// the next step's operands are requested into registers right after the barrier, stay in flight under the whole step's MFMAs,
-// and are written into the other LDS stage (ds_write_b128, the image the DMA produced) at the end of the step.
-// Addresses are a scalar base (A or B: a piece never straddles) plus a 32-bit lane offset, so staging costs PPW offset
-// registers + 4 PPW data registers.  Host contract in addition to gemm_big_k's: M * lda and N * ldb bytes below 4 GiB.
-// ------------------------------------------------------------------------------------------------
-template <typename TO, int TM, int TN, int WN>
-__global__ __launch_bounds__(128 * WN, 1) void gemm_reg_k(const GemmP p) {
-    typedef BigTile<TM, TN, WN> G;
-    constexpr int BM = G::BM, BN = G::BN;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / WN, wc = wave % WN;
-    const int kt0 = p.partial ? blockIdx.y * (p.k_per_split / BK) : 0;
-    const int nk = p.partial ? min(p.K / BK - kt0, p.k_per_split / BK) : p.K / BK;
-    const int nwg = p.tiles_m * p.tiles_n;
-    long m0, n0;
-    {
-        const int id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
-        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-        m0 = (long)(wg / p.tiles_n) * BM; n0 = (long)(wg % p.tiles_n) * BN;
-    }
-    const int fr = lane & 15, fg = lane >> 4;
-    int offA[2], offB[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-        const int slot = ((ks * 4 + fg) ^ (fr >> 1)) << 4;
-        offA[ks] = (wr * (BM / 2) + fr) * 128 + slot;
-        offB[ks] = (BM + wc * (BN / WN) + fr) * 128 + slot;
-    }
-    // ---- staging: piece q = wave + NW*i covers rows 8q .. 8q+7 of the stacked [A rows ; B rows] image
-    const char* const baseA = (const char*)p.A + (long)kt0 * BK * 2;
-    const char* const baseB = (const char*)p.B + (long)kt0 * BK * 2;
-    unsigned voff[G::PPW];
-#pragma unroll
-    for (int i = 0; i < G::PPW; i++) {
-        const int q = wave + G::NW * i;
-        const bool isA = q * 8 < BM;                                       // wave-uniform
-        const int lrow = q * 8 + (lane >> 3) - (isA ? 0 : BM);
-        const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);
-        long gr = (isA ? m0 : n0) + lrow;
-        const long lim = (isA ? p.M : p.N) - 1;
-        if (gr > lim) gr = lim;
-        voff[i] = (unsigned)(gr * (isA ? p.lda : p.ldb) * 2 + chunk * 16);
-    }
-    mm_u4_t stg[G::PPW];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < G::PPW; i++) {
-            const int q = wave + G::NW * i;
-            if (q < G::PIECES) stg[i] = *reinterpret_cast<const mm_u4_t*>((q * 8 < BM ? baseA : baseB) + (long)kt * (BK * 2) + voff[i]);
-        }
-    };
-    auto lwrite = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < G::PPW; i++) {
-            const int q = wave + G::NW * i;
-            if (q < G::PIECES) *reinterpret_cast<mm_u4_t*>(smem + buf * G::STAGE_BYTES + q * 1024 + lane * 16) = stg[i];
-        }
-    };
-    f32x4_t acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t fa[TM], fb[TN];
-    auto rd = [&](const unsigned char* ls, int ks) {
-#pragma unroll
-        for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const bf16x8_t*>(ls + offB[ks] + j * 2048);
-#pragma unroll
-        for (int i = 0; i < TM; i++) fa[i] = *reinterpret_cast<const bf16x8_t*>(ls + offA[ks] + i * 2048);
-    };
-    auto mm = [&]() {
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    };
-    constexpr int LAB_BASE = G::LDS_BYTES;
-    if (nk > 0) { gload(0); lwrite(0); }
-    const bool late = p.stagger && wave >= G::NW / 2;                      // scalar
-    if (!late) {
-        for (int kt = 0; kt < nk; kt++) {
-            STAMP(kt, 0);
-            __syncthreads();                               // stage kt written by everyone; everyone is done with the other stage
-            STAMP(kt, 1);
-            if (kt + 1 < nk) gload(kt + 1);
-            STAMP(kt, 2);
-            const unsigned char* ls = smem + (kt & 1) * G::STAGE_BYTES;
-            rd(ls, 0); mm();
-            STAMP(kt, 3);
-            rd(ls, 1); mm();
-            STAMP(kt, 4);
-            if (kt + 1 < nk) lwrite((kt + 1) & 1);
-            STAMP(kt, 5);
-        }
-    } else {
-        for (int kt = 0; kt < nk; kt++) {
-            STAMP(kt, 0);
-            __syncthreads();
-            STAMP(kt, 1);
-            if (kt + 1 < nk) gload(kt + 1);
-            STAMP(kt, 2);
-            const unsigned char* ls = smem + (kt & 1) * G::STAGE_BYTES;
-            if (kt > 0) mm();                              // second half step of tile kt-1 (fragments held in registers)
-            STAMP(kt, 3);
-            rd(ls, 0); mm();
-            STAMP(kt, 4);
-            rd(ls, 1);                                     // held across the next barrier
-            if (kt + 1 < nk) lwrite((kt + 1) & 1);
-            STAMP(kt, 5);
-        }
-        if (nk > 0) mm();
-    }
-    STAMP_DUMP();
-    __syncthreads();
-    big_epilogue<TO, TM, TN, G::EPI_ROW>(p, acc, smem + G::STAGE_BYTES + wave * G::EPI_WAVE, m0 + wr * (BM / 2), n0 + wc * (BN / WN), lane);
-}
-
+#ifdef GEMM_LAB   // experimental main loops live outside the product source: benchmarks/gemm_lab_loops.inc (lab builds only)
+#include "../../benchmarks/gemm_lab_loops.inc"
 #endif  // GEMM_LAB
 
 // split-K second stage with the FULL fused epilogue: sum the slabs in a fixed order, then bias / act / mul / gamma / rowscale /
