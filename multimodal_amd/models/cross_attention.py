@@ -26,15 +26,25 @@ class CrossAttentionBlock(nn.Module):
     def forward(self, query, key_value):
         if self.use_rope and self.rope_freqs is not None:
             raise NotImplementedError("the reference's rope module (models/rope.py) does not exist; use_rope=False only")
-        if self.dropout.p != 0.0:
-            raise NotImplementedError("attention-probability dropout (reference :42 applies it even in eval) is not "
-                                      "implemented in the fused kernel; construct with dropout=0.0")
         dt = FN.get_compute_dtype()
         B, Tq, C = query.shape
         Tkv = key_value.shape[1]
         q = F.linear(query.to(dt), self.linear_q.weight.to(dt), self.linear_q.bias.to(dt))
         k = F.linear(key_value.to(dt), self.linear_k.weight.to(dt), self.linear_k.bias.to(dt))
         v = F.linear(key_value.to(dt), self.linear_v.weight.to(dt), self.linear_v.bias.to(dt))
+        if self.dropout.p != 0.0:
+            # The class's own default (dropout=0.1).  The reference passes dropout_p=self.dropout.p to SDPA in EVERY mode
+            # (:42), i.e. it drops attention probabilities in eval too, and applies the module dropout to the projected output
+            # (:45, train mode only).  Dropping probabilities needs the [B,H,Tq,Tkv] matrix, which the fused kernel never
+            # forms, so this (dead-code, parity-unpinned, random by construction) case forms it with plain tensor products and
+            # torch's generator; the dropout-free case below stays on the fused kernel.
+            H, d = self.num_heads, C // self.num_heads
+            qh, kh, vh = (t.view(B, -1, H, d).transpose(1, 2) for t in (q, k, v))
+            prob = torch.softmax((qh.float() @ kh.float().transpose(-1, -2)) * (d ** -0.5), dim=-1)
+            prob = F.dropout(prob, self.dropout.p, training=True)
+            a = (prob.to(dt) @ vh).transpose(1, 2).reshape(B, Tq, C)
+            o = self.dropout(F.linear(a, self.out_proj.weight.to(dt), self.out_proj.bias.to(dt)))
+            return FN.LayerNorm.apply(query.to(dt) + o, self.norm.weight, self.norm.bias)
         # K3 computes full attention of S rows over S keys when every row is a prompt row (prompt_len = S).  Keys must not be
         # padded (a padded key row would be seen), queries may: the queries go through in chunks of at most Tkv rows, each
         # padded to Tkv (the padded query rows are computed and dropped).
