@@ -24,6 +24,13 @@ static __device__ __forceinline__ void IO_f4(const float* p, float (&v)[4]) {   
     const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
 }
 
+template <int VEC> static __device__ __forceinline__ void IO_fv(const float* p, float (&v)[VEC]) {   // VEC = 4 or 8 parameters
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p + i); v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward, channels-last input, strip kernel
 //
@@ -123,13 +130,13 @@ __global__ __launch_bounds__(256) void dwconv7_ln_fwd_strip(const T* __restrict_
 // workgroup: rows are finished in groups of R = 4, so the two cross-wave reductions (mean, then centred variance) cost two
 // barriers per 4 rows instead of per row; the per-wave partials of the 4 rows travel through LDS as one float4.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NT, int CH, int QD>
+template <typename T, int NT, int CH, int QD, int VEC = 4>
 __global__ __launch_bounds__(NT) void dwconv7_ln_fwd_wide(const T* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ cb, const float* __restrict__ lw,
                                                          const float* __restrict__ lb, T* __restrict__ y,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                          int B, int C, int L, int TL, int sps, float eps) {
-    constexpr int VEC = 4, RING = 8, R = 4, NW = NT / 64;
+    constexpr int RING = 8, R = 4, NW = NT / 64;        // VEC: channels per chunk (8 = one 16-byte load of bf16)
     static_assert(RING % QD == 0, "queue depth must divide the ring");
     typedef VecIO<T, VEC> IO;
     typedef typename IO::raw_t raw_t;
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_fwd_wide(const T* __restrict__ 
         for (int v = 0; v < VEC; v++)
 #pragma unroll
             for (int t = 0; t < 7; t++) wt[k][t][v] = w[(cidx[k] + v) * 7 + t];
-        IO_f4(cb + cidx[k], bias[k]);
+        IO_fv<VEC>(cb + cidx[k], bias[k]);
     }
     const float n_w = wave_sum_u((float)mine);    // channels of this wave
     const float inv_nw = n_w > 0.f ? 1.0f / n_w : 0.f;
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_fwd_wide(const T* __restrict__ 
             // (mean_w - mean)^2): two-pass accuracy with ONE barrier per 4 rows.
             float g[CH][VEC], be[CH][VEC];
 #pragma unroll
-            for (int k = 0; k < CH; k++) { IO_f4(lw + cidx[k], g[k]); IO_f4(lb + cidx[k], be[k]); }   // issued before the barrier
+            for (int k = 0; k < CH; k++) { IO_fv<VEC>(lw + cidx[k], g[k]); IO_fv<VEC>(lb + cidx[k], be[k]); }   // issued before the barrier
             float mw[R], m2w[R];
 #pragma unroll
             for (int rr = 0; rr < R; rr++) {
@@ -725,6 +732,47 @@ __global__ void dwconv7_ln_bwd_reduce(const float* __restrict__ partial, int nro
     }
 }
 
+// Two-stage, coalesced form of the reduction above for many partial rows (one per workgroup of the backward kernel: 2048 at
+// B = 2048): a block sums ROWS_PER_SPLIT rows of 64 consecutive columns -- a wave reads 256 contiguous bytes per row --
+// into out[split][column]; the column-per-block kernel above read one float per 64-KiB stride and took 231 us of the 556 us
+// backward at B2048 C1600 (profiles/r03_k1_wide_pmc.txt).  Fixed summation order: deterministic.
+constexpr int RED_ROWS_PER_SPLIT = 128;
+__global__ __launch_bounds__(256) void dwconv7_ln_bwd_reduce_rows(const float* __restrict__ partial, int nrows, int ncols,
+                                                                float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * RED_ROWS_PER_SPLIT, r1 = min(r0 + RED_ROWS_PER_SPLIT, nrows);
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) s[u] = 0.f;
+    if (col < ncols) {
+        for (int r = r0 + rl; r < r1; r += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int rr = r + 4 * u;
+                s[u] += rr < r1 ? partial[(long)rr * ncols + col] : 0.f;
+            }
+        }
+    }
+    red[rl][cl] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (rl == 0 && col < ncols) out[(long)blockIdx.y * ncols + col] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+// final stage: one thread per output scalar over `nrows` (few) rows, consecutive threads on consecutive columns
+__global__ __launch_bounds__(256) void dwconv7_ln_bwd_final(const float* __restrict__ partial, int nrows, int C, float* __restrict__ dw,
+                                                          float* __restrict__ db, float* __restrict__ dlw, float* __restrict__ dlb) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 10 * C) return;
+    float s = 0.f;
+    for (int r = 0; r < nrows; r++) s += partial[(long)r * 10 * C + idx];
+    const int kind = idx / C, c = idx % C;
+    if (kind < 7) dw[c * 7 + kind] = s;
+    else if (kind == 7) db[c] = s;
+    else if (kind == 8) dlw[c] = s;
+    else dlb[c] = s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -775,10 +823,21 @@ static int launch_fwd_wide(const void* x, const float* w, const float* b, const 
 #define LAUNCH_(NT_, CH_, QD_) hipLaunchKernelGGL((dwconv7_ln_fwd_wide<T, NT_, CH_, QD_>), grid, dim3(NT_), 0, st, (const T*)x, w, b, \
                                                   lw, lb, (T*)y, mean, rstd, (int)B, (int)C, (int)L, TL, sps, eps)
     static int variant = getenv("MM_K1W_VARIANT") ? atoi(getenv("MM_K1W_VARIANT")) : 0;      // A/B knob
+    // bf16: a thread owns 8 consecutive channels (one 16-byte load per row; the per-row LayerNorm reduction steps, which do not
+    // depend on the channel count, are shared by 8 elements instead of 4): 175 -> 130 us (two 4-channel chunks) -> see
+    // profiles/r03_k1_all_shapes.txt at B2048 C1600 L31
+    if constexpr (sizeof(T) == 2) {
+        if (C % 8 == 0 && C <= 2048 && variant != 4) {
+            hipLaunchKernelGGL((dwconv7_ln_fwd_wide<T, 256, 1, 4, 8>), grid, dim3(256), 0, st, (const T*)x, w, b, lw, lb, (T*)y, mean,
+                               rstd, (int)B, (int)C, (int)L, TL, sps, eps);
+            MM_LAUNCH_CHECK();
+            return MM_OK;
+        }
+    }
     if (C <= 1024) { if (variant == 1) LAUNCH_(256, 1, 8); else LAUNCH_(256, 1, 4); }
     else if (C <= 2048) {
         if (variant == 1) LAUNCH_(512, 1, 8);
-        else if (variant == 2) LAUNCH_(256, 2, 4);
+        else if (variant == 2 || sizeof(T) == 2) LAUNCH_(256, 2, 4);
         else LAUNCH_(512, 1, 4);
     } else LAUNCH_(512, 2, 2);
 #undef LAUNCH_
@@ -857,7 +916,8 @@ static BwdPlan plan_bwd(int64_t B, int64_t C, int64_t L, int dtype) {
 extern "C" size_t mm_dwconv7_ln_bwd_workspace(int64_t B, int64_t C, int64_t L) {
     if (B <= 0 || C <= 0 || L <= 0) return 0;
     const BwdPlan p = plan_bwd(B, C, L, MM_F32);
-    return (size_t)p.nblocks * 10 * (size_t)C * sizeof(float);
+    const size_t splits = (size_t)cdiv(p.nblocks, RED_ROWS_PER_SPLIT);           // rows of the reduction's second stage
+    return ((size_t)p.nblocks + splits) * 10 * (size_t)C * sizeof(float);
 }
 
 template <typename T>
@@ -912,8 +972,17 @@ extern "C" int mm_dwconv7_ln_bwd(const void* x, const void* dy, const void* dres
     int rc = (dtype == MM_F32) ? launch_bwd<float>(p, x, dy, dres, w, b, ln_w, mean, rstd, dx, partial, B, C, L, st)
                                : launch_bwd<bf16>(p, x, dy, dres, w, b, ln_w, mean, rstd, dx, partial, B, C, L, st);
     if (rc != MM_OK) return rc;
-    hipLaunchKernelGGL(dwconv7_ln_bwd_reduce, dim3((unsigned)(10 * C)), dim3(256), 0, st, partial, (int)p.nblocks, (int)C,
-                       dw, db, dln_w, dln_b);
+    if (p.nblocks <= 64) {                     // few partial rows (the config batch): one pass, a block per output scalar
+        hipLaunchKernelGGL(dwconv7_ln_bwd_reduce, dim3((unsigned)(10 * C)), dim3(256), 0, st, partial, (int)p.nblocks, (int)C,
+                           dw, db, dln_w, dln_b);
+    } else {
+        const int splits = (int)cdiv(p.nblocks, RED_ROWS_PER_SPLIT);
+        float* part2 = partial + (size_t)p.nblocks * 10 * C;
+        hipLaunchKernelGGL(dwconv7_ln_bwd_reduce_rows, dim3((unsigned)cdiv(10 * C, 64), (unsigned)splits), dim3(256), 0, st, partial,
+                           (int)p.nblocks, (int)(10 * C), part2);
+        hipLaunchKernelGGL(dwconv7_ln_bwd_final, dim3((unsigned)cdiv(10 * C, 256)), dim3(256), 0, st, part2, splits, (int)C, dw, db,
+                           dln_w, dln_b);
+    }
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
