@@ -1547,10 +1547,15 @@ struct DecP {
 
 template <typename T, int VEC, int CH>
 __global__ __launch_bounds__(256) void decode_attn_k(const DecP p) {
-    constexpr int SC_MAX = 1024;
-    __shared__ float sc[4][SC_MAX];
-    __shared__ float rq[4][512], rk[4][512];
+    // LDS sized by the launch for THIS cache length and head_dim ([4 waves][Smax scores | d | d floats]): with the static
+    // worst case (1024 scores, d = 512: 32 KiB) five workgroups held 160 KiB and nothing else could share the CU
+    extern __shared__ __attribute__((aligned(16))) float k4_lds[];
+    const int dpad = (p.d + 3) & ~3;
+    float* sc_w = k4_lds + (threadIdx.x >> 6) * (p.Smax + 2 * dpad);
+    float* rq_w = sc_w + p.Smax;
+    float* rk_w = rq_w + dpad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    (void)wave;
     const int li = lane & 15, grp = lane >> 4;
     const int bh = blockIdx.x * 4 + wave;
     if (bh >= p.B * p.H) return;                       // wave-uniform
@@ -1562,15 +1567,15 @@ __global__ __launch_bounds__(256) void decode_attn_k(const DecP p) {
     T* kc = (T*)p.kc + (long)bh * p.Smax * d;
     T* vc = (T*)p.vc + (long)bh * p.Smax * d;
     // ---- rotate q and k_new at position pos (through LDS: the partner element lives in another lane)
-    for (int c = lane; c < d; c += 64) { rq[wave][c] = to_f(qg[c]); rk[wave][c] = to_f(kng[c]); }
+    for (int c = lane; c < d; c += 64) { rq_w[c] = to_f(qg[c]); rk_w[c] = to_f(kng[c]); }
     __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): own LDS writes landed (single wave owns its rows)
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < half; i += 64) {
         const float c = p.cos_t[(long)pos * half + i], s = p.sin_t[(long)pos * half + i];
-        const float a = rq[wave][i], bb = rq[wave][i + half];
-        rq[wave][i] = a * c - bb * s; rq[wave][i + half] = bb * c + a * s;
-        const float a2 = rk[wave][i], b2 = rk[wave][i + half];
-        rk[wave][i] = a2 * c - b2 * s; rk[wave][i + half] = b2 * c + a2 * s;
+        const float a = rq_w[i], bb = rq_w[i + half];
+        rq_w[i] = a * c - bb * s; rq_w[i + half] = bb * c + a * s;
+        const float a2 = rk_w[i], b2 = rk_w[i + half];
+        rk_w[i] = a2 * c - b2 * s; rk_w[i + half] = b2 * c + a2 * s;
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
@@ -1584,8 +1589,8 @@ __global__ __launch_bounds__(256) void decode_attn_k(const DecP p) {
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
             const bool ok = c + v < d;
-            qv[k][v] = ok ? to_f(from_f<T>(rq[wave][c + v])) : 0.f;
-            knv[k][v] = ok ? to_f(from_f<T>(rk[wave][c + v])) : 0.f;
+            qv[k][v] = ok ? to_f(from_f<T>(rq_w[c + v])) : 0.f;
+            knv[k][v] = ok ? to_f(from_f<T>(rk_w[c + v])) : 0.f;
             vnv[k][v] = ok ? to_f(vng[c + v]) : 0.f;
         }
     }
@@ -1634,7 +1639,7 @@ __global__ __launch_bounds__(256) void decode_attn_k(const DecP p) {
                     }
                 if (it + PF < nit) issue(kc, it + PF, buf[u]);
                 dot = group_sum<16>(dot) * p.scale;
-                if (j < pos) { if (li == 0) sc[wave][j] = dot; mx = fmaxf(mx, dot); }
+                if (j < pos) { if (li == 0) sc_w[j] = dot; mx = fmaxf(mx, dot); }
             }
         }
     }
@@ -1667,7 +1672,7 @@ __global__ __launch_bounds__(256) void decode_attn_k(const DecP p) {
             if (it < nit) {                                  // wave-uniform
                 const int j = it * 4 + grp;
                 const bool ok = j < pos;
-                const float x = sc[wave][ok ? j : 0];
+                const float x = sc_w[ok ? j : 0];
                 const float w = ok ? (stable ? stable_s_f(x) : __expf(x - mx)) : 0.f;
                 lsum += w;
 #pragma unroll
@@ -1792,7 +1797,8 @@ static int decode_launch(const void* q, const void* k_new, const void* v_new, vo
     const dim3 grid((unsigned)cdiv(B * H, 4));
     hipStream_t st = (hipStream_t)stream;
     // vector width: the cache rows are d elements apart, so VEC must divide d
-#define L_(T_, VEC_, CH_) hipLaunchKernelGGL((decode_attn_k<T_, VEC_, CH_>), grid, dim3(256), 0, st, p)
+    const size_t lds = (size_t)4 * (Smax + 2 * ((d + 3) & ~3)) * sizeof(float);      // <= 4 * (1024 + 1024) * 4 = 32 KiB
+#define L_(T_, VEC_, CH_) hipLaunchKernelGGL((decode_attn_k<T_, VEC_, CH_>), grid, dim3(256), lds, st, p)
     if (dtype == MM_BF16) {
         const bool a16 = ((uintptr_t)kcache % 16 == 0) && ((uintptr_t)vcache % 16 == 0) && ((uintptr_t)o % 16 == 0);
         if (d % 8 == 0 && a16) { if (d <= 128) L_(bf16, 8, 1); else if (d <= 256) L_(bf16, 8, 2); else L_(bf16, 8, 4); }

@@ -40,6 +40,15 @@ def _layer_weights(layer, dt):
 
 
 _DECODE_GEMM = os.environ.get("MM_DECODE_GEMM", "auto")    # A/B knob: "mm" = every product on libmmhip, "lib" = none
+_DECODE_SPLIT = int(os.environ.get("MM_DECODE_SPLIT", "2"))     # A/B knob: independent decode loops a large batch is cut into (1 = none)
+_extra_streams: dict = {}
+
+
+class KVCacheView:
+    """Batch slice of a KVCache (contiguous: the batch is the leading dimension)."""
+
+    def __init__(self, k, v, Smax):
+        self.k, self.v, self.Smax = k, v, Smax
 
 
 def _lin(x2, w, b, b16=None, act=0, res=None, out_dtype=None, square=False):
@@ -204,32 +213,45 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
     emb = dec.smiles_embed.weight
 
     tokens = torch.full((B, steps + 1), bos_id, dtype=torch.long, device=dev)
-    # ---- prefill over [prompt ; BOS]
-    x = torch.cat([prompt, emb[tokens[:, :1]].to(dt)], dim=1)                  # [B, P+1, E]
-    S0 = P + 1
-    for li, layer in enumerate(dec.layers):
-        w = weights[li]
-        cos_t, sin_t = layer.rotary_emb.half_tables(Smax)
-        M0 = B * S0
-        xa, _, _ = ops.layernorm_fwd(x, layer.attn_norm.weight, layer.attn_norm.bias)
-        # the big prefill products stay on the library where it wins (N = 3E, 4E: DESIGN.md 4), the N = E products with
-        # their bias + residual run on the large-tile kernel, as in the training forward
-        qkv = torch.addmm(w["bqkv16"], xa.view(M0, E), w["wqkv"].t()).view(B, S0, 3, E)
-        rot = layer.rotary_ndims
-        if dt == torch.bfloat16 and rot > 0:       # rotate q,k once in place: cache fill becomes a copy, K3 runs its fast form
-            ops.rope_inplace(qkv.view(B, S0, 3 * E)[:, :, :2 * E], 2 * H, rot, cos_t, sin_t)
-            rot = 0
-        ops.kv_cache_fill(qkv[:, :, 1], qkv[:, :, 2], cache.k[li], cache.v[li], H, rot, cos_t, sin_t)
-        a, _ = ops.prefix_attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], H, rot, P, cos_t, sin_t, layer.use_stablemax)
-        x = _lin(a.view(M0, E), w["wo"], w["bo"], res=x.view(M0, E), square=True).view(B, S0, E)
-        xf, _, _ = ops.layernorm_fwd(x, layer.mlp_norm.weight, layer.mlp_norm.bias)
-        u = ops.relu2_fwd(torch.addmm(w["b116"], xf.view(M0, E), w["w1"].t()))
-        x = _lin(u, w["w2"], w["b2"], res=x.view(M0, E), square=True).view(B, S0, E)      # prefill: N = E on the large-tile kernel
-    xt, _, _ = ops.layernorm_fwd(x[:, -1].contiguous(), dec.final_norm.weight, dec.final_norm.bias)
-    nxt = ops.argmax_rows(_lin(xt, w_out, b_out, b_out16, out_dtype=torch.float32))     # :102
+    for layer in dec.layers:
+        layer.rotary_emb.half_tables(Smax)         # cached tables exist before any other stream asks for them
+
+    def prefill(pr, kcs, vcs):
+        """Prefix-LM pass over [prompt ; BOS] for the rows of `pr` [b, P, E] on the current stream: fills the rows' cache slices
+        (kcs / vcs: per-layer [b, H, Smax, d]) and returns the first generated ids [b]."""
+        nb = pr.shape[0]
+        bos = torch.full((nb, 1), bos_id, dtype=torch.long, device=dev)
+        x = torch.cat([pr, emb[bos].to(dt)], dim=1)                            # [b, P+1, E]
+        S0 = P + 1
+        M0 = nb * S0
+        for li, layer in enumerate(dec.layers):
+            w = weights[li]
+            cos_t, sin_t = layer.rotary_emb.half_tables(Smax)
+            xa, _, _ = ops.layernorm_fwd(x, layer.attn_norm.weight, layer.attn_norm.bias)
+            # the big prefill products stay on the library where it wins (N = 3E, 4E: DESIGN.md 4), the N = E products with
+            # their bias + residual run on the large-tile kernel, as in the training forward
+            qkv = torch.addmm(w["bqkv16"], xa.view(M0, E), w["wqkv"].t()).view(nb, S0, 3, E)
+            rot = layer.rotary_ndims
+            if dt == torch.bfloat16 and rot > 0:   # rotate q,k once in place: cache fill becomes a copy, K3 runs its fast form
+                ops.rope_inplace(qkv.view(nb, S0, 3 * E)[:, :, :2 * E], 2 * H, rot, cos_t, sin_t)
+                rot = 0
+            ops.kv_cache_fill(qkv[:, :, 1], qkv[:, :, 2], kcs[li], vcs[li], H, rot, cos_t, sin_t)
+            a, _ = ops.prefix_attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], H, rot, P, cos_t, sin_t, layer.use_stablemax)
+            x = _lin(a.view(M0, E), w["wo"], w["bo"], res=x.view(M0, E), square=True).view(nb, S0, E)
+            xf, _, _ = ops.layernorm_fwd(x, layer.mlp_norm.weight, layer.mlp_norm.bias)
+            u = ops.relu2_fwd(torch.addmm(w["b116"], xf.view(M0, E), w["w1"].t()))
+            x = _lin(u, w["w2"], w["b2"], res=x.view(M0, E), square=True).view(nb, S0, E)  # prefill: N = E on the large-tile kernel
+        xt, _, _ = ops.layernorm_fwd(x[:, -1].contiguous(), dec.final_norm.weight, dec.final_norm.bias)
+        return ops.argmax_rows(_lin(xt, w_out, b_out, b_out16, out_dtype=torch.float32))     # :102
+
+    use_graph = bool(graph)
+    nsplit = _DECODE_SPLIT if (_DECODE_SPLIT > 1 and not use_graph and B >= 128 * _DECODE_SPLIT and B % _DECODE_SPLIT == 0) else 1
+    n_done = 1
+    # the prefill runs once for the whole batch (MFMA-bound: cutting it in two only made its products smaller -- measured
+    # 741k against 753k tokens/s with the halves prefilled on their own streams)
+    nxt = prefill(prompt, cache.k, cache.v)
     tokens[:, 1] = nxt
     finished = nxt == eos_id
-    n_done = 1
     # ---- decode steps
     def decode_step(cur, pos):
         """One token for every row: cur [B] ids at position pos-1 -> argmax ids at pos (pos: int, or int32 device scalar)."""
@@ -250,7 +272,6 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
         xt, _, _ = ops.layernorm_fwd(h, dec.final_norm.weight, dec.final_norm.bias)
         return ops.argmax_rows(_lin(xt, w_out, b_out, b_out16, out_dtype=torch.float32))
 
-    use_graph = bool(graph)
     if use_graph and steps > 2:
         cur_s = nxt.clone()
         pos_dev = torch.tensor([P + 1], dtype=torch.int32, device=dev)
@@ -284,17 +305,43 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
             g.replay()
             n_done = t + 1
     else:
-        ids = torch.empty((steps + 1, B), dtype=torch.long, device=dev)          # row t+1: argmax output and next input
-        ids[0] = bos_id
-        ids[1] = nxt
+        # Rows are independent, so a large batch is cut into TWO halves that run their decode loops free of each other, one on
+        # the current stream and one on the side stream (no event between them until the end).  A step alternates an
+        # HBM-bound kernel (K4: the cache read, half of a step's time) with short latency-bound products (M = batch rows);
+        # two loops out of phase put one half's cache read beside the other half's products (K4's LDS is sized per launch
+        # for that: with its static 32 KiB five of its workgroups filled a CU's LDS and no product could move in).  Same
+        # kernels on the same rows: the ids are those of the single loop (tests/test_decode_plan_gpu.py).
         emb_dt = FN.cached_operand((emb,), dt)
-        plan = _StepPlan(dec, weights, cache, w_out, b_out, b_out16, emb_dt, ids, B, dt, dev, Smax)
+        main = torch.cuda.current_stream(dev)
+        streams = [main] + ([FN.side_stream(dev)] if nsplit >= 2 else [])
+        while len(streams) < nsplit:
+            key = (dev, len(streams))
+            if key not in _extra_streams:
+                _extra_streams[key] = torch.cuda.Stream(device=dev)
+            streams.append(_extra_streams[key])
+        hb = B // nsplit
+        parts = []
+        for j, st in enumerate(streams):
+            st.wait_stream(main)                                                 # the prefill's cache rows and first ids
+            with torch.cuda.stream(st):
+                view = KVCacheView([kc[j * hb: (j + 1) * hb] for kc in cache.k], [vc[j * hb: (j + 1) * hb] for vc in cache.v], Smax)
+                ids = torch.empty((steps + 1, hb), dtype=torch.long, device=dev)   # row t+1: argmax output and next input
+                ids[0] = bos_id
+                ids[1] = nxt[j * hb: (j + 1) * hb]
+                parts.append((st, ids, _StepPlan(dec, weights, view, w_out, b_out, b_out16, emb_dt, ids, hb, dt, dev, Smax)))
         for t in range(1, steps):
-            if early_stop and t % sync_every == 0 and bool((ids[1: t + 1] == eos_id).any(0).all()):   # :113 (every few steps)
+            if early_stop and t % sync_every == 0 and all(bool((ids[1: t + 1] == eos_id).any(0).all()) for _, ids, _ in parts):   # :113
                 break
-            plan.step(t, P + t)
+            for st, ids, plan in parts:
+                with torch.cuda.stream(st):
+                    plan.step(t, P + t)
             n_done = t + 1
-        tokens[:, 1: n_done + 1] = ids[1: n_done + 1].t()
+        for j, (st, ids, plan) in enumerate(parts):
+            with torch.cuda.stream(st):
+                tokens[j * hb: (j + 1) * hb, 1: n_done + 1] = ids[1: n_done + 1].t()
+            main.wait_stream(st)
+            for tns in (ids, tokens):
+                tns.record_stream(st)
     if was_training:
         model.train()
     return tokens[:, : n_done + 1]

@@ -31,8 +31,9 @@ _ws_cache = {}
 
 
 def workspace(nbytes: int, device, tag: str = "ws") -> Tensor:
-    """Grow-only byte workspace per (device, tag); the caller owns it, the library never allocates."""
-    key = (device, tag)
+    """Grow-only byte workspace per (device, tag, current stream); the caller owns it, the library never allocates.  Keyed by
+    stream: kernels of two streams may run beside each other (generate()'s two half-batch loops) and must not share scratch."""
+    key = (device, tag, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
