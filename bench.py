@@ -27,11 +27,11 @@ CONFIGS = {
     "test_config": dict(E=768, H=4, L=8, sm=True, max_seq=95, max_nmr=190, max_mem=32),
     "real_config_mup": dict(E=2048, H=4, L=8, sm=True, max_seq=95, max_nmr=190, max_mem=32),
 }
-K1_PMC = os.path.join("profiles", "r02_k1_pmc.json")
-K4_PMC = os.path.join("profiles", "r02_k4_pmc.json")
-ATTN_PMC = os.path.join("profiles", "r02_attn3_pmc.json")
-ATTN_KERNELS = "attn_fwd3_k / attn_delta_k + attn_bwd_dq3_k + attn_bwd_dkv3_k"
-ATTN_KERNELS_WIDE = "prefix_attn_fwd_k / prefix_attn_bwd_dq4_k + prefix_attn_bwd_dkv4_k (head_dim > 192)"
+K1_PMC = os.path.join("profiles", "r03_k1_pmc.json")
+K4_PMC = os.path.join("profiles", "r03_k4_pmc.json")
+ATTN_PMC = os.path.join("profiles", "r03_attn_d100_pmc.json")
+ATTN_KERNELS = "attn_fwd_r_k / attn_bwd_dq_r_k + attn_bwd_dkv_r_k (whole head resident in LDS; attention_res.hip)"
+ATTN_KERNELS_WIDE = "attn_fwd_w_k / attn_delta_k + attn_bwd_dq_w_k + attn_bwd_dkv_w_k (head_dim 512; attention_wide.hip)"
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (same guide)
 
@@ -187,7 +187,7 @@ def attn_roofline(device, B=32, H=16, d=100, N=190, T=94):
     """K3 / K3b at the local_config shape (S = 31+N+T = 315, prompt 221, stablemax, bf16, q/k pre-rotated as in the
     model): SURVEY 8d flops 4*B*S^2*E forward, 2.5x that backward (mask sparsity not discounted), against the dense bf16
     MFMA peak.  Per score the stablemax weight costs 5-6 vector instructions against 2 MFMAs' worth of matrix work per 64 scores,
-    so vector issue, not the matrix cores, bounds these kernels (counters: profiles/r02_attn3_pmc.json)."""
+    so vector issue, not the matrix cores, bounds these kernels (counters: profiles/r03_attn_d100_pmc.json)."""
     from multimodal_amd import ops
     E, S, P = H * d, 31 + N + T, 31 + N
     rot = int(d * 0.5)

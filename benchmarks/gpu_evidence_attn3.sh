@@ -19,7 +19,7 @@ for shape in "${SH[@]}"; do
       --lds=attn_fwd_w:135168,attn_bwd_dq_w:135168,attn_bwd_dkv_w:137728 $O/$tag/pass1 $O/$tag/pass2 $O/$tag/pass3 > /dev/null 2>&1
   else
     python3 benchmarks/attn_pmc_summary.py $O/r03_attn_${tag}_pmc.json --kernels=attn_fwd_r,attn_bwd_dq_r,attn_bwd_dkv_r,attn_delta \
-      --lds=attn_fwd_r:143360,attn_bwd_dq_r:143360,attn_bwd_dkv_r:145920 $O/$tag/pass1 $O/$tag/pass2 $O/$tag/pass3 > /dev/null 2>&1
+      --lds=attn_fwd_r:143584,attn_bwd_dq_r:143584,attn_bwd_dkv_r:146144 $O/$tag/pass1 $O/$tag/pass2 $O/$tag/pass3 > /dev/null 2>&1
   fi
   f=$(find $O/$tag/trace -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && grep -E "attn_|Name" "$f" | cut -c1-200 > $O/r03_attn_${tag}_kernel_stats.csv
