@@ -238,7 +238,7 @@ def decode_roofline(device, B=1024, H=8, d=128, Smax=238):
     if (B, H, d, Smax) == (1024, 8, 128, 238) and os.path.exists(pmc):
         with open(pmc) as fh:
             traffic = int(json.load(fh)["traffic_bytes_per_launch"])
-    return {"kernel": "decode_attn_k", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    return {"kernel": "decode_attn1_k", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "launch_us": round(t * 1e6, 2),
             "traffic_source": (K4_PMC + " (rocprofv3 --pmc passes over benchmarks/decode_pmc.py, same shape; not "
                                "re-measured in this run)") if traffic is not None else None,

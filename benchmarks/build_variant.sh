@@ -1,16 +1,11 @@
 #!/bin/bash
-# build_variant.sh <tag> [extra hipcc flags...]: an A/B build of libmmhip.so with extra -D flags ->
-# multimodal_amd/lib/libmmhip_<tag>.so (select it at run time with MM_LIB=<path>).
+# build_variant.sh NAME SRC "EXTRA FLAGS": libmmhip with one source rebuilt under extra flags -> benchmarks/bin/libmmhip_NAME.so (A/B runs via MM_LIB)
 set -e
-tag=$1; shift
 cd "$(dirname "$0")/../multimodal_amd/csrc"
-mkdir -p build_$tag ../lib
-for f in *.hip; do
-  o=build_$tag/${f%.hip}.o
-  if [ ! -f $o ] || [ $f -nt $o ] || [ -n "$REBUILD" ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -ffp-contract=off "$@" -c $f -o $o &
-  fi
-done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libmmhip_$tag.so build_$tag/*.o
-echo built ../lib/libmmhip_$tag.so
+mkdir -p ../../benchmarks/bin /tmp/mmvar
+extra=""
+case "$2" in attention_fast|attention_wide|attention_res) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -ffp-contract=off $extra $3 -c $2.hip -o /tmp/mmvar/$2_$1.o
+objs=$(ls build/*.o | grep -v "build/$2.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../benchmarks/bin/libmmhip_$1.so $objs /tmp/mmvar/$2_$1.o
+echo built benchmarks/bin/libmmhip_$1.so

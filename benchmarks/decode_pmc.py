@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs only the K4 (decode_attn_k) launches of bench.py's roofline_decode leg (same shape), for rocprofv3 --pmc passes:
+"""Runs only the K4 (decode_attn1_k) launches of bench.py's roofline_decode leg (same shape), for rocprofv3 --pmc passes:
     rocprofv3 --pmc FETCH_SIZE -d out_f -- python3 benchmarks/decode_pmc.py
     rocprofv3 --pmc WRITE_SIZE -d out_w -- python3 benchmarks/decode_pmc.py
 benchmarks/pmc_summary.py turns the two counter CSVs into profiles/*_k4_pmc.json (per-launch HBM bytes)."""

@@ -6,7 +6,7 @@ O=gpurun_out/r3/ev
 mkdir -p $O
 # ---- 1. HBM traffic of the two HBM roofline kernels (separate FETCH_SIZE / WRITE_SIZE passes)
 for k in k1 k4; do
-  if [ $k = k1 ]; then scr=benchmarks/k1_pmc.py; kn=dwconv7_ln_fwd_strip; else scr=benchmarks/decode_pmc.py; kn=decode_attn_k; fi
+  if [ $k = k1 ]; then scr=benchmarks/k1_pmc.py; kn=dwconv7_ln_fwd_strip; else scr=benchmarks/decode_pmc.py; kn=decode_attn1_k; fi
   timeout -s KILL 120 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/${k}_f -o p -- python3 $scr > $O/${k}_f.log 2>&1 || exit 1
   timeout -s KILL 120 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/${k}_w -o p -- python3 $scr > $O/${k}_w.log 2>&1 || exit 1
   python3 benchmarks/pmc_summary.py $O/${k}_f $O/${k}_w $kn $O/r03_${k}_pmc.json > /dev/null || exit 1

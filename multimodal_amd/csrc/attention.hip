@@ -1713,6 +1713,188 @@ __global__ __launch_bounds__(256) void decode_attn_k(const DecP p) {
     }
 }
 
+// K4, one pass (bf16): the K row and the V row of a position are in flight together and every 16-lane group keeps its
+// own running softmax (max, sum, output), merged across the four groups at the end; stablemax needs no max at all.
+// No score round trip through LDS and no K-pass -> V-pass boundary: with all B*H waves resident and of equal length,
+// that boundary (and the start-up) was chip-wide idle HBM time.  The walk is branch-free: every iteration issues its
+// loads (rows past the end clamp to the last cached row and weigh 0; columns past d clamp to column 0 against a zero q),
+// so the compiler counts the loads in flight exactly (behind `if (more rows)` it fell back to vmcnt(0) per iteration);
+// the cache base is wave-uniform (scalar registers) and a row's offset a 32-bit lane value.
+// benchmarks/k4_pattern.hip: the cache walk alone reads at 6.0-6.1 TB/s; the two-pass kernel reached 4.8-5.0.
+template <typename T, int VEC, int CH, bool STABLE>
+__global__ __launch_bounds__(256) void decode_attn1_k(const DecP p) {
+    extern __shared__ __attribute__((aligned(16))) float k4_lds[];          // [4 waves][d | d floats]: the rotation's partner exchange
+    const int dpad = (p.d + 3) & ~3;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* rq_w = k4_lds + wave * (2 * dpad);
+    float* rk_w = rq_w + dpad;
+    const int li = lane & 15, grp = lane >> 4;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= p.B * p.H) return;                       // wave-uniform
+    const int b = bh / p.H, h = bh % p.H;
+    const int d = p.d, half = p.rot >> 1, pos = p.pos_dev ? min(max(*p.pos_dev, 0), p.Smax - 1) : p.pos;
+    const T* qg = (const T*)p.q + (long)b * p.ld + (long)h * d;
+    const T* kng = (const T*)p.kn + (long)b * p.ld + (long)h * d;
+    const T* vng = (const T*)p.vn + (long)b * p.ld + (long)h * d;
+    T* kc = (T*)p.kc + (long)bh * p.Smax * d;
+    T* vc = (T*)p.vc + (long)bh * p.Smax * d;
+    typedef typename VecIO<T, VEC>::raw_t raw_t;
+#ifndef K4_PF
+#define K4_PF 4
+#endif
+    constexpr int PF = CH >= 4 ? 1 : (CH == 2 ? 2 : K4_PF);           // positions ahead (a K row and a V row each)
+    constexpr int DMAX = CH * VEC * 16, NQ = (DMAX + 63) / 64, NH = (DMAX / 2 + 63) / 64;      // the launch picks CH with d <= DMAX
+    static_assert(DMAX <= 512, "head_dim <= 512");
+    bool cok[CH];
+    unsigned colb[CH];                                                 // byte offset of this lane's chunk k inside a row (0 if past d)
+#pragma unroll
+    for (int k = 0; k < CH; k++) { const int c = (k * 16 + li) * VEC; cok[k] = c < d; colb[k] = cok[k] ? c * (unsigned)sizeof(T) : 0u; }
+    // ---- the token's own vectors first (the waits are in issue order), then the first cache rows, which depend on nothing
+    float qraw[NQ], kraw[NQ];                                          // lane + 64 * i < d
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { const int c = lane + 64 * i; if (c < d) { qraw[i] = to_f(qg[c]); kraw[i] = to_f(kng[c]); } }
+    raw_t vnr[CH];
+#pragma unroll
+    for (int k = 0; k < CH; k++) vnr[k] = VecIO<T, VEC>::load_raw((const T*)((const char*)vng + colb[k]));
+    float cr[NH], sr[NH];                                              // lane + 64 * i < half
+#pragma unroll
+    for (int i = 0; i < NH; i++) { const int c = lane + 64 * i; if (c < half) { cr[i] = p.cos_t[(long)pos * half + c]; sr[i] = p.sin_t[(long)pos * half + c]; } }
+    const int nit = (pos + 3) >> 2;
+    const unsigned rowb = (unsigned)d * (unsigned)sizeof(T);          // Smax * d * sizeof(T) <= 1024 * 512 * 4: 32-bit offsets
+    auto issue = [&](int it, raw_t (&dk)[CH], raw_t (&dv)[CH]) {
+        const unsigned r = (unsigned)min(it * 4 + grp, pos - 1) * rowb;
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            // non-temporal: the rows are read once per step; as ordinary loads they also evicted the step's weights from the
+            // last-level cache (K4 alone 177 -> 164 us, the whole decode step 0.97 -> 0.88 ms)
+            dk[k] = __builtin_nontemporal_load((const raw_t*)((const char*)kc + (r + colb[k])));
+            dv[k] = __builtin_nontemporal_load((const raw_t*)((const char*)vc + (r + colb[k])));
+        }
+    };
+    raw_t bk[PF][CH], bv[PF][CH];
+    if (nit > 0) {                                       // pos = 0: no cached row exists to clamp to
+#pragma unroll
+        for (int u = 0; u < PF; u++) issue(u, bk[u], bv[u]);
+    }
+    // ---- rotate q and k_new at position pos (through LDS: the partner element lives in another lane)
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { const int c = lane + 64 * i; if (c < d) { rq_w[c] = qraw[i]; rk_w[c] = kraw[i]; } }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): own LDS writes landed (single wave owns its rows)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < NH; i++) {
+        const int c = lane + 64 * i;
+        if (c < half) {
+            const float a = rq_w[c], bb = rq_w[c + half];
+            rq_w[c] = a * cr[i] - bb * sr[i]; rq_w[c + half] = bb * cr[i] + a * sr[i];
+            const float a2 = rk_w[c], b2 = rk_w[c + half];
+            rk_w[c] = a2 * cr[i] - b2 * sr[i]; rk_w[c + half] = b2 * cr[i] + a2 * sr[i];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    // registers: this lane's slice of q (rounded to T like the prefill kernel does; 0 past d), k_new, v_new
+    float qv[CH][VEC], knv[CH][VEC], vnv[CH][VEC];
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int c = cok[k] ? (k * 16 + li) * VEC : 0;                // d % VEC == 0 (launch): a chunk is inside the row or past it
+        VecIO<T, VEC>::unpack(vnr[k], vnv[k]);
+#pragma unroll
+        for (int v = 0; v < VEC; v += 4) {
+            const mm_f4_t tq = *reinterpret_cast<const mm_f4_t*>(rq_w + c + v), tk = *reinterpret_cast<const mm_f4_t*>(rk_w + c + v);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                qv[k][v + e] = cok[k] ? to_f(from_f<T>(tq[e])) : 0.f;
+                knv[k][v + e] = to_f(from_f<T>(tk[e]));
+            }
+        }
+    }
+    if (grp == 0) {                                      // append to the cache
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+            if (cok[k]) {
+                const int c = (k * 16 + li) * VEC;
+                VecIO<T, VEC>::store(kc + (long)pos * d + c, knv[k]);
+                VecIO<T, VEC>::store(vc + (long)pos * d + c, vnv[k]);
+            }
+    }
+    // ---- the walk.  Softmax in base 2: x2 = q.k * scale * log2(e), weights exp2(x2 - running max).
+    const float sc = STABLE ? p.scale : p.scale * 1.44269504088896f;
+    float oacc[CH][VEC];
+    float lsum = 0.f, m = -1e30f;
+#pragma unroll
+    for (int k = 0; k < CH; k++)
+#pragma unroll
+        for (int v = 0; v < VEC; v++) oacc[k][v] = 0.f;
+    auto take = [&](bool ok, float x, const float (&vv)[CH][VEC]) {
+        float w;
+        if (STABLE) {
+            w = ok ? stable_s_fast(x) : 0.f;
+        } else {
+            const float mn = ok ? fmaxf(m, x) : m;
+            const float al = __builtin_amdgcn_exp2f(m - mn);
+            w = ok ? __builtin_amdgcn_exp2f(x - mn) : 0.f;
+            m = mn; lsum *= al;
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+#pragma unroll
+                for (int v = 0; v < VEC; v++) oacc[k][v] *= al;
+        }
+        lsum += w;
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+#pragma unroll
+            for (int v = 0; v < VEC; v++) oacc[k][v] = fmaf(w, vv[k][v], oacc[k][v]);
+    };
+    {                                                    // the new token's own key/value: one more position of group 0, taken first (its registers die here)
+        float dn = 0.f;
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+#pragma unroll
+            for (int v = 0; v < VEC; v++) dn = fmaf(qv[k][v], knv[k][v], dn);
+        take(grp == 0, group_sum<16>(dn) * sc, vnv);
+    }
+    for (int it0 = 0; it0 < nit; it0 += PF) {            // iterations past nit (the last round) re-read the last row and weigh 0
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int it = it0 + u;
+            float kv[CH][VEC], vv[CH][VEC];
+#pragma unroll
+            for (int k = 0; k < CH; k++) { VecIO<T, VEC>::unpack(bk[u][k], kv[k]); VecIO<T, VEC>::unpack(bv[u][k], vv[k]); }
+            issue(it + PF, bk[u], bv[u]);
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+#pragma unroll
+                for (int v = 0; v < VEC; v++) dot = fmaf(qv[k][v], kv[k][v], dot);
+            take(it * 4 + grp < pos, group_sum<16>(dot) * sc, vv);
+        }
+    }
+    float f = 1.f;
+    if (!STABLE) {
+        float M = fmaxf(m, __shfl_xor(m, 16));
+        M = fmaxf(M, __shfl_xor(M, 32));
+        f = __builtin_amdgcn_exp2f(m - M);               // a group without positions: m = -1e30, f = 0
+    }
+    lsum *= f;
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    const float inv = 1.0f / (STABLE ? fmaxf(lsum, 1e-9f) : lsum);
+    T* og = (T*)p.o + (long)b * p.H * d + (long)h * d;
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        float r[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            float t = oacc[k][v] * f;
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            r[v] = t * inv;
+        }
+        if (grp == 0 && cok[k]) VecIO<T, VEC>::store(og + (k * 16 + li) * VEC, r);
+    }
+}
+
 template <typename T>
 __global__ void kv_cache_fill_k(const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ kc, T* __restrict__ vc,
                                 const float* __restrict__ cos_t, const float* __restrict__ sin_t, int B, int H, int S, int d,
@@ -1799,7 +1981,17 @@ static int decode_launch(const void* q, const void* k_new, const void* v_new, vo
     // vector width: the cache rows are d elements apart, so VEC must divide d
     const size_t lds = (size_t)4 * (Smax + 2 * ((d + 3) & ~3)) * sizeof(float);      // <= 4 * (1024 + 1024) * 4 = 32 KiB
 #define L_(T_, VEC_, CH_) hipLaunchKernelGGL((decode_attn_k<T_, VEC_, CH_>), grid, dim3(256), lds, st, p)
-    if (dtype == MM_BF16) {
+    // bf16: the one-pass kernel (LDS only for the rotation); f32 keeps the two-pass kernel and its exact op order
+    static const bool two_pass = getenv("MM_K4_TWO_PASS") != nullptr;          // A/B switch
+    const size_t lds1 = (size_t)4 * 2 * ((d + 3) & ~3) * sizeof(float);
+#define L1_(VEC_, CH_) do { if (mode == MM_ATTN_STABLEMAX) hipLaunchKernelGGL((decode_attn1_k<bf16, VEC_, CH_, true>), grid, dim3(256), lds1, st, p); \
+                            else hipLaunchKernelGGL((decode_attn1_k<bf16, VEC_, CH_, false>), grid, dim3(256), lds1, st, p); } while (0)
+    if (dtype == MM_BF16 && !two_pass) {
+        const bool a16 = ((uintptr_t)kcache % 16 == 0) && ((uintptr_t)vcache % 16 == 0) && ((uintptr_t)o % 16 == 0);
+        if (d % 8 == 0 && a16) { if (d <= 128) L1_(8, 1); else if (d <= 256) L1_(8, 2); else L1_(8, 4); }
+        else if (d % 4 == 0) { if (d <= 64) L1_(4, 1); else if (d <= 128) L1_(4, 2); else if (d <= 256) L1_(4, 4); else L1_(4, 8); }
+        else MM_FAIL(MM_ERR_UNSUPPORTED, "decode_attn: head_dim %lld must be a multiple of 4", (long long)d);
+    } else if (dtype == MM_BF16) {
         const bool a16 = ((uintptr_t)kcache % 16 == 0) && ((uintptr_t)vcache % 16 == 0) && ((uintptr_t)o % 16 == 0);
         if (d % 8 == 0 && a16) { if (d <= 128) L_(bf16, 8, 1); else if (d <= 256) L_(bf16, 8, 2); else L_(bf16, 8, 4); }
         else if (d % 4 == 0) { if (d <= 64) L_(bf16, 4, 1); else if (d <= 128) L_(bf16, 4, 2); else if (d <= 256) L_(bf16, 4, 4); else L_(bf16, 4, 8); }
@@ -1809,6 +2001,7 @@ static int decode_launch(const void* q, const void* k_new, const void* v_new, vo
         else MM_FAIL(MM_ERR_UNSUPPORTED, "decode_attn: head_dim %lld must be a multiple of 4", (long long)d);
     } else MM_FAIL(MM_ERR_ARG, "decode_attn: bad dtype %d", dtype);
 #undef L_
+#undef L1_
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
