@@ -217,21 +217,30 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
         layer.rotary_emb.half_tables(Smax)         # cached tables exist before any other stream asks for them
 
     def prefill(pr, kcs, vcs):
-        """Prefix-LM pass over [prompt ; BOS] for the rows of `pr` [b, P, E] on the current stream: fills the rows' cache slices
-        (kcs / vcs: per-layer [b, H, Smax, d]) and returns the first generated ids [b]."""
+        """Pass over the PROMPT rows `pr` [b, P, E] on the current stream (prompt positions see each other and nothing else, so
+        they do not depend on what follows): fills the rows' cache slices (kcs / vcs: per-layer [b, H, Smax, d]).  The BOS
+        token is not part of it -- it is decode step 0 at position P -- and of the last layer only the keys and values of the
+        prompt are computed: nothing reads that layer's outputs at prompt positions (its attention, out-projection and MLP over
+        B*P rows were a fifth of the prefill's products)."""
         nb = pr.shape[0]
-        bos = torch.full((nb, 1), bos_id, dtype=torch.long, device=dev)
-        x = torch.cat([pr, emb[bos].to(dt)], dim=1)                            # [b, P+1, E]
-        S0 = P + 1
+        x = pr.contiguous()
+        S0 = P
         M0 = nb * S0
         for li, layer in enumerate(dec.layers):
             w = weights[li]
             cos_t, sin_t = layer.rotary_emb.half_tables(Smax)
             xa, _, _ = ops.layernorm_fwd(x, layer.attn_norm.weight, layer.attn_norm.bias)
+            rot = layer.rotary_ndims
+            if li == len(dec.layers) - 1:
+                kv = torch.addmm(w["bqkv16"][E:], xa.view(M0, E), w["wqkv"][E:].t()).view(nb, S0, 2, E)
+                if dt == torch.bfloat16 and rot > 0:
+                    ops.rope_inplace(kv.view(nb, S0, 2 * E)[:, :, :E], H, rot, cos_t, sin_t)
+                    rot = 0
+                ops.kv_cache_fill(kv[:, :, 0], kv[:, :, 1], kcs[li], vcs[li], H, rot, cos_t, sin_t)
+                break
             # the big prefill products stay on the library where it wins (N = 3E, 4E: DESIGN.md 4), the N = E products with
             # their bias + residual run on the large-tile kernel, as in the training forward
             qkv = torch.addmm(w["bqkv16"], xa.view(M0, E), w["wqkv"].t()).view(nb, S0, 3, E)
-            rot = layer.rotary_ndims
             if dt == torch.bfloat16 and rot > 0:   # rotate q,k once in place: cache fill becomes a copy, K3 runs its fast form
                 ops.rope_inplace(qkv.view(nb, S0, 3 * E)[:, :, :2 * E], 2 * H, rot, cos_t, sin_t)
                 rot = 0
@@ -239,19 +248,16 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
             a, _ = ops.prefix_attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], H, rot, P, cos_t, sin_t, layer.use_stablemax)
             x = _lin(a.view(M0, E), w["wo"], w["bo"], res=x.view(M0, E), square=True).view(nb, S0, E)
             xf, _, _ = ops.layernorm_fwd(x, layer.mlp_norm.weight, layer.mlp_norm.bias)
-            u = ops.relu2_fwd(torch.addmm(w["b116"], xf.view(M0, E), w["w1"].t()))
+            u = ops.relu2_fwd(torch.addmm(w["b116"], xf.view(M0, E), w["w1"].t()))     # fused on libmmhip it measured slower (prefill 27.5 vs 25 ms)
             x = _lin(u, w["w2"], w["b2"], res=x.view(M0, E), square=True).view(nb, S0, E)  # prefill: N = E on the large-tile kernel
-        xt, _, _ = ops.layernorm_fwd(x[:, -1].contiguous(), dec.final_norm.weight, dec.final_norm.bias)
-        return ops.argmax_rows(_lin(xt, w_out, b_out, b_out16, out_dtype=torch.float32))     # :102
 
     use_graph = bool(graph)
     nsplit = _DECODE_SPLIT if (_DECODE_SPLIT > 1 and not use_graph and B >= 128 * _DECODE_SPLIT and B % _DECODE_SPLIT == 0) else 1
-    n_done = 1
+    n_done = 0
     # the prefill runs once for the whole batch (MFMA-bound: cutting it in two only made its products smaller -- measured
     # 741k against 753k tokens/s with the halves prefilled on their own streams)
-    nxt = prefill(prompt, cache.k, cache.v)
-    tokens[:, 1] = nxt
-    finished = nxt == eos_id
+    prefill(prompt, cache.k, cache.v)
+    finished = torch.zeros(B, dtype=torch.bool, device=dev)
     # ---- decode steps
     def decode_step(cur, pos):
         """One token for every row: cur [B] ids at position pos-1 -> argmax ids at pos (pos: int, or int32 device scalar)."""
@@ -272,10 +278,10 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
         xt, _, _ = ops.layernorm_fwd(h, dec.final_norm.weight, dec.final_norm.bias)
         return ops.argmax_rows(_lin(xt, w_out, b_out, b_out16, out_dtype=torch.float32))
 
-    if use_graph and steps > 2:
-        cur_s = nxt.clone()
-        pos_dev = torch.tensor([P + 1], dtype=torch.int32, device=dev)
-        col_dev = torch.tensor([2], dtype=torch.long, device=dev)
+    if use_graph and steps > 1:
+        cur_s = torch.full((B,), bos_id, dtype=torch.long, device=dev)
+        pos_dev = torch.tensor([P], dtype=torch.int32, device=dev)
+        col_dev = torch.tensor([1], dtype=torch.long, device=dev)
 
         def body():
             new = decode_step(cur_s, pos_dev)
@@ -289,8 +295,8 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(cur_stream)
         with torch.cuda.stream(warm):
-            body()                                                             # t = 1, eagerly (library warm-up before capture)
-        n_done = 2
+            body()                                                             # t = 0 (the BOS token), eagerly: library warm-up before capture
+        n_done = 1
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(warm):          # bare capture: torch.cuda.graph() would also synchronize, collect garbage
             g.capture_begin()                  # and empty the allocator cache on every generate() call
@@ -299,7 +305,7 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
             finally:
                 g.capture_end()
         cur_stream.wait_stream(warm)
-        for t in range(2, steps):
+        for t in range(1, steps):
             if early_stop and t % sync_every == 0 and bool(finished.all()):    # :113 (checked every few steps)
                 break
             g.replay()
@@ -327,10 +333,9 @@ def greedy_generate(model, nmr_tokens: Optional[torch.Tensor], ir_data: torch.Te
                 view = KVCacheView([kc[j * hb: (j + 1) * hb] for kc in cache.k], [vc[j * hb: (j + 1) * hb] for vc in cache.v], Smax)
                 ids = torch.empty((steps + 1, hb), dtype=torch.long, device=dev)   # row t+1: argmax output and next input
                 ids[0] = bos_id
-                ids[1] = nxt[j * hb: (j + 1) * hb]
                 parts.append((st, ids, _StepPlan(dec, weights, view, w_out, b_out, b_out16, emb_dt, ids, hb, dt, dev, Smax)))
-        for t in range(1, steps):
-            if early_stop and t % sync_every == 0 and all(bool((ids[1: t + 1] == eos_id).any(0).all()) for _, ids, _ in parts):   # :113
+        for t in range(steps):                                                   # step 0: the BOS token at position P
+            if early_stop and t > 0 and t % sync_every == 0 and all(bool((ids[1: t + 1] == eos_id).any(0).all()) for _, ids, _ in parts):   # :113
                 break
             for st, ids, plan in parts:
                 with torch.cuda.stream(st):
