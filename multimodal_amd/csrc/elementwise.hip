@@ -195,9 +195,10 @@ __global__ __launch_bounds__(256) void og_adamw_k(const mm_param_desc* __restric
                                                  float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s,
                                                  const float* __restrict__ hyper) {
     if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2s = hyper[2]; }      // step-dependent scalars from device memory (HIP graphs)
-    const int t = chunk_tensor[blockIdx.x];
+    const int blk = blockIdx.x;          // (walking the chunks in reverse, to meet the reduce pass's last reads in the last-level cache: 2 % alone, nothing in the step)
+    const int t = chunk_tensor[blk];
     const mm_param_desc d = descs[t];
-    const long off = chunk_off[blockIdx.x];
+    const long off = chunk_off[blk];
     const long end = min(d.n, off + (long)chunk_elems);
     const float proj = coef ? coef[3 * t] : 0.f;
     float scale = coef ? coef[3 * t + 1] : 1.f;
