@@ -97,6 +97,35 @@ def test_decode_attn_matches_full_recompute(case, stablemax, dtype):
         assert rel_err(o.float().cpu(), ref[:, pos]) < TOL[dtype], pos
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("stablemax", [True, False])
+@pytest.mark.parametrize("case", [(2, 3, 128, 9), (1, 2, 100, 7), (1, 1, 512, 6)])
+def test_decode_attn_from_an_empty_poisoned_cache(case, stablemax, dtype):
+    """K4 from position 0 on (no cached row at all, then 1, 2, 3 ... rows: fewer than one 4-row iteration, ragged last
+    iterations) with every cache element NaN before it is written: rows at or beyond `pos` must never reach the result
+    (the one-pass kernel clamps the rows of its last iterations and weighs them 0)."""
+    from multimodal_amd import ops
+    B, H, d, S = case
+    E = H * d
+    rot = int(d * 0.5)
+    rot -= rot % 2
+    dev = torch.device("cuda:0")
+    qkv = _rand(B, S, 3, E, seed=5, scale=1.5).to(dtype)
+    q, k, v = (qkv[:, :, i].float() for i in range(3))
+    ref = _oracle(q, k, v, H, rot, 0, stablemax)                       # no prefix: causal
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2).float() / rot))
+    Smax = S + 2
+    cos_t, sin_t = ops.rope_tables(inv.to(dev), Smax)
+    qkv_d = qkv.to(dev)
+    kc = torch.full((B, H, Smax, d), float("nan"), dtype=dtype, device=dev)
+    vc = torch.full_like(kc, float("nan"))
+    for pos in range(S):
+        o = ops.decode_attn(qkv_d[:, pos, 0], qkv_d[:, pos, 1], qkv_d[:, pos, 2], kc, vc, H, rot, pos, cos_t, sin_t, stablemax)
+        assert torch.isfinite(o).all(), pos
+        assert rel_err(o.float().cpu(), ref[:, pos]) < TOL[dtype], pos
+    assert torch.isnan(kc[:, :, S:]).all() and torch.isfinite(kc[:, :, :S]).all()
+
+
 @pytest.mark.parametrize("stablemax", [True, False])
 @pytest.mark.parametrize("case", CASES)
 def test_prefix_attn_prerotated_bf16_fast_path(case, stablemax):
