@@ -28,27 +28,44 @@ if os.environ.get("MM_OPT_DEFER", "1") == "1":
     opt.defer_into_next_forward(model, model.decoder.layers)
 ir, nmr, tgt = bench.synth_batch(c, 32, dev, 1234)
 crit = torch.nn.CrossEntropyLoss(ignore_index=0)
-NAMES = ["step start", "forward issued", "loss issued", "backward returned", "finish() returned", "opt.step() returned"]
+NAMES = ["step start", "encoder forward issued", "forward issued", "loss issued", "encoder backward begins", "backward returned", "finish() returned", "opt.step() returned"]
+_rec = [None]
+
+
+def _mark(i):
+    rec = _rec[0]
+    if rec is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        rec.append((i, time.perf_counter(), ev))
+
+
+def _enc_hook(mod, inp, out):
+    _mark(1)
+    t = out[0] if isinstance(out, (tuple, list)) else out
+    if t.requires_grad:
+        t.register_hook(lambda g: _mark(4))
+
+
+model.encoder.register_forward_hook(_enc_hook)
 
 
 def step(rec=None):
-    def mark(i):
-        if rec is not None:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            rec.append((i, time.perf_counter(), ev))
+    _rec[0] = rec
+    mark = _mark
     mark(0)
     dp.zero_grad()
     logits = model(nmr, ir, tgt[:, :-1], None)
-    mark(1)
-    loss = crit(logits.reshape(-1, logits.size(-1)), tgt[:, 1:].reshape(-1))
     mark(2)
-    dp.scale_loss(loss).backward()
+    loss = crit(logits.reshape(-1, logits.size(-1)), tgt[:, 1:].reshape(-1))
     mark(3)
-    dp.finish()
-    mark(4)
-    opt.step()
+    dp.scale_loss(loss).backward()
     mark(5)
+    dp.finish()
+    mark(6)
+    opt.step()
+    mark(7)
+    _rec[0] = None
 
 
 for _ in range(8):
@@ -65,7 +82,7 @@ for rep in range(6):
     step(rec)
     step()                      # the next step keeps the queue full, as in the training loop
     torch.cuda.synchronize()
-    rows.append([(i, (h - h0) * 1e3, origin.elapsed_time(ev)) for i, h, ev in rec])
+    rows.append({i: ((h - h0) * 1e3, origin.elapsed_time(ev)) for i, h, ev in rec})
 # steady-state step time
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -77,7 +94,7 @@ ms = (time.perf_counter() - t0) / 20 * 1e3
 med = lambda xs: sorted(xs)[len(xs) // 2]
 out = {"ms_per_step": round(ms, 3), "boundaries": []}
 for k, name in enumerate(NAMES):
-    host = med([r[k][1] for r in rows])
-    gpu = med([r[k][2] for r in rows])
+    host = med([r[k][0] for r in rows])
+    gpu = med([r[k][1] for r in rows])
     out["boundaries"].append({"boundary": name, "host_issue_ms": round(host, 3), "gpu_reached_ms": round(gpu, 3), "gpu_lag_ms": round(gpu - host, 3)})
 print(json.dumps(out, indent=1))

@@ -192,3 +192,50 @@ def test_load_state_dict_completes_pending_updates_first():
         st = opt.state[w]
         i = next(j for j, p in enumerate(p for g in opt.param_groups for p in g["params"]) if p is w)
         assert torch.equal(st["exp_avg"], saved["base_optimizer"]["state"][i]["exp_avg"].to(DEV))   # ... not on the loaded ones
+
+
+def test_config_size_deferred_equals_plain_while_the_encoder_runs_beside_it():
+    """At the config size (E1600 H16 L8, batch 32, bf16) the deferred updates take 2 ms on the side stream and really run
+    beside the next encoder forward's MFMA kernels.  Round 3 found them NOT repeatable there: the reduce pass's sum of g^2,
+    paired into v_pk_fma_f32 by the compiler, came out 1e-4 lower on some chunks whenever gemm_k waves shared the chip
+    (benchmarks/opt_race_check.py) -- the small model above never showed it.  elementwise.hip is built without packed-f32
+    pairing since; the loss sequence and every decoder parameter must equal the plain optimizer's bit for bit."""
+    import bench
+    import multimodal_amd as mm
+    from multimodal_amd.dp import DataParallel
+    from multimodal_amd.optim import OrthoGradAdamW
+    c = bench.CONFIGS["local_config"]
+
+    def run(defer, steps=5):
+        with mm.compute_dtype(torch.bfloat16):
+            torch.manual_seed(0)
+            model = bench.build_model(c, DEV).train()
+            dp = DataParallel(model)
+            opt = OrthoGradAdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, ortho=True,
+                                 ortho_eps=1e-8, rescale=True)
+            if defer:
+                opt.defer_into_next_forward(model, model.decoder.layers)
+            ir, nmr, tgt = bench.synth_batch(c, 32, DEV, 1234)
+            crit = torch.nn.CrossEntropyLoss(ignore_index=0)
+            torch.manual_seed(1)
+            losses = []
+            for _ in range(steps):
+                dp.zero_grad()
+                logits = model(nmr, ir, tgt[:, :-1], None)
+                loss = crit(logits.reshape(-1, logits.size(-1)), tgt[:, 1:].reshape(-1))
+                dp.scale_loss(loss).backward()
+                dp.finish()
+                opt.step()
+                losses.append(loss.detach().clone())
+            opt.flush_deferred(wait=True)
+            torch.cuda.synchronize()
+            params = {n: p.detach().clone() for n, p in model.decoder.named_parameters()}
+        del model, dp, opt
+        torch.cuda.empty_cache()
+        return torch.stack(losses), params
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert torch.equal(l0, l1), (l0.tolist(), l1.tolist())
+    bad = [n for n in p0 if not torch.equal(p0[n], p1[n])]
+    assert not bad, bad[:8]
