@@ -98,6 +98,12 @@ def update(beside):
         blk = bb.stages[1][0]
         for _ in range(60):
             _ops.dwconv7_ln_fwd(STAGE_IN[1], blk.dwconv.weight, blk.dwconv.bias, blk.norm.weight, blk.norm.bias)
+    elif beside == "gemmbig":
+        for _ in range(30):
+            _ops.gemm(BA, BW, BA.shape[0], BW.shape[0], BA.shape[1], bias=BB)
+    elif beside == "attn":
+        for _ in range(30):
+            _ops.prefix_attn_fwd(AQ[:, :, 0], AQ[:, :, 1], AQ[:, :, 2], 16, 0, 221, ACOS, ASIN, True, save_lse=True)
     elif beside == "add":
         for _ in range(40):
             BIG.add_(1)
@@ -144,6 +150,11 @@ from multimodal_amd import ops as _ops
 GA = torch.randn(3968, 256, device=dev, dtype=torch.bfloat16)
 GW = torch.randn(1024, 256, device=dev, dtype=torch.bfloat16)
 GB = torch.zeros(1024, device=dev)
+BA = torch.randn(10080, 1600, device=dev, dtype=torch.bfloat16)
+BW = torch.randn(1600, 1600, device=dev, dtype=torch.bfloat16)
+BB = torch.zeros(1600, device=dev)
+AQ = (torch.rand(32, 315, 3, 1600, device=dev) - 0.5).to(torch.bfloat16)
+ACOS, ASIN = _ops.rope_tables(1.0 / (10000 ** (torch.arange(0, 50, 2, device=dev).float() / 50)), 315)
 ref = update("")
 again = update("")
 print("alone vs alone: tensors differing:", len([n for n, a, b in zip(names, ref, again) if not torch.equal(a, b)]), flush=True)
