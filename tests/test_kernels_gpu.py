@@ -329,3 +329,29 @@ def test_colsum():
         x = _rand(1234, 777, seed=1).to(dtype)
         s = ops.colsum(x.to(_dev()), 1234, 777)
         assert rel_err(s.cpu(), x.float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_scale", [True, False])
+@pytest.mark.parametrize("shape", [(32, 250, 64), (32, 125, 128), (32, 62, 256), (32, 31, 1600), (3, 13, 72), (1, 5, 2048), (2, 7, 36)])
+def test_layerscale_bwd_all_stage_shapes(shape, with_scale, dtype):
+    """LayerScale + DropPath backward (models/convnext.py:44-47 through autograd): dz = dout * gamma * s[row // L],
+    dgamma = sum dout * s * z, db2 = sum dz -- on every encoder stage shape (bf16: the 8-channels-per-lane kernel of round 3),
+    a ragged shape, the widest row it takes, and C % 8 != 0 (the scalar kernel)."""
+    from multimodal_amd import ops
+    B, Ln, C = shape
+    M = B * Ln
+    dev = torch.device("cuda:0")
+    dout = _rand(M, C, seed=1).to(dtype)
+    z = _rand(M, C, seed=2).to(dtype)
+    gamma = _rand(C, seed=3) * 0.5
+    s = (torch.rand(B, generator=torch.Generator().manual_seed(4)) > 0.3).float() / 0.7 if with_scale else None
+    d32 = dout.float() * (s.repeat_interleave(Ln)[:, None] if with_scale else 1.0)
+    ref_dz = d32 * gamma
+    ref_dg = (d32 * z.float()).sum(0)
+    ref_db = ref_dz.to(dtype).float().sum(0) if dtype == torch.float32 else ref_dz.sum(0)
+    dz, dg, db = ops.layerscale_bwd(dout.to(dev), z.to(dev), gamma.to(dev), s.to(dev) if with_scale else None, Ln)
+    torch.cuda.synchronize()
+    assert rel_err(dz.float().cpu(), ref_dz) < TOL[dtype]
+    assert rel_err(dg.cpu(), ref_dg) < 1e-4, (dg.cpu() - ref_dg).abs().max()
+    assert rel_err(db.cpu(), ref_db) < 1e-4
