@@ -161,7 +161,11 @@ int mm_rope_inplace(void* x, const float* cos_t, const float* sin_t, int64_t B, 
  * train_autoregressive.py:97-101); equals row `pos` of K3 by the argument of SURVEY.md A9.
  * q,k_new,v_new: [B][H][d] for the token at absolute position pos (ld_qkv = elements between b rows).
  * RoPE is applied to q and k_new; k_new (rotated) and v_new are appended at slot pos of
- * kcache/vcache [B][H][Smax][d]; o: [B][H][d] = attention of q over slots 0..pos. */
+ * kcache/vcache [B][H][Smax][d]; o: [B][H][d] = attention of q over slots 0..pos.
+ * d <= 512, d % 4 == 0, Smax <= 1024.  Slots at or beyond pos are never read (the caches may hold anything there).
+ * bf16 runs in one pass (K and V rows of a position read together, non-temporally; the softmax weights are exp2 of
+ * base-2 scores against a running maximum per 16-lane group, merged at the end); f32 keeps two passes and the op order
+ * of the prefill kernel. */
 int mm_decode_attn(const void* q, const void* k_new, const void* v_new, void* kcache, void* vcache, void* o,
                    const float* cos_t, const float* sin_t, int64_t B, int64_t H, int64_t d, int64_t rot,
                    int64_t pos, int64_t Smax, int64_t ld_qkv, int mode, int dtype, void* stream);
