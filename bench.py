@@ -284,9 +284,9 @@ def greedy_bench(device, world, rank):
             "decode_loop_roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                      "frac": round(ach / HBM_PEAK_GBPS, 4), "ms_per_decode_step": round(t_loop / n_dec * 1e3, 4),
                                      "kv_bytes_per_step_avg": kv // n_dec, "weight_bytes_per_step": wts // n_dec,
-                                     "note": "K4 (the KV read) is about half of the step at 0.61-0.64 of HBM; the rest is "
-                                             "16 short latency-bound GEMMs (M = batch rows) and LayerNorm; the step is issued "
-                                             "from prepared launches (0.18 ms of host time per step): GPU-bound"}}
+                                     "note": "K4 (the KV read, one pass, 0.76 of HBM alone) is about 0.56 ms of the 0.88 ms step; the rest is "
+                                             "16 short latency-bound GEMMs per half batch and LayerNorm; the two half-batch loops are "
+                                             "issued from prepared launches on two streams: GPU-bound"}}
 
 
 def train_leg(c, device, batch, dtype, steps, warmup, rank=0, backend="auto"):
