@@ -98,7 +98,8 @@ extern "C" int mm_layerscale_bwd(const void* dout, const void* z, const float* g
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MM_BF16 && C % 8 == 0 && C <= 2048 && (((uintptr_t)dout | (uintptr_t)z | (uintptr_t)dz) % 16) == 0) {
         const int rp = 256 / (int)(C / 8);                          // rows a block walks together
-        const int rpc = (int)cdiv(cdiv(M, chunks), rp) * rp;        // a chunk is whole passes of the block
+        const int target = chunks < 64 ? chunks : 64;               // few chunks: the second stage walks them one after the other
+        const int rpc = (int)cdiv(cdiv(M, target), rp) * rp;        // a chunk is whole passes of the block
         const int nchunks = (int)cdiv(M, rpc);                      // <= chunks: the workspace holds them
         hipLaunchKernelGGL(layerscale_bwd_v_k, dim3((unsigned)nchunks), dim3(256), 0, st, (const bf16*)dout, (const bf16*)z, gamma, rowscale,
                            (int)rows_per_scale, (bf16*)dz, (float*)workspace, (int)M, (int)C, rpc);
