@@ -380,15 +380,22 @@ __global__ __launch_bounds__(256) void colsum_stage1v_k(const T* __restrict__ x,
 }
 // out[n] = sum_c part[c][n]: a block covers 64 columns, 4 chunk groups
 __global__ __launch_bounds__(256) void colsum_stage2_k(const float* __restrict__ part, float* __restrict__ out, int nchunks, int N) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + cl;
+    // 16 columns x 16 chunk groups per block: with up to 160 chunks a 4-way split left 40 dependent loads per thread (15-25 us for
+    // a few hundred KB, on the backward's critical path after every relu^2 / LayerNorm backward); fixed summation order
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + cl;
     float s = 0.f;
     if (n < N)
-        for (int c = g; c < nchunks; c += 4) s += part[(long)c * N + n];
+        for (int c = g; c < nchunks; c += 16) s += part[(long)c * N + n];
     red[g][cl] = s;
     __syncthreads();
-    if (g == 0 && n < N) out[n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    if (g == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t += red[k][cl];
+        out[n] = t;
+    }
 }
 static int colsum_chunks(int64_t M) { int64_t c = cdiv(M, 64); if (c > 160) c = 160; if (c < 1) c = 1; return (int)c; }
 extern "C" size_t mm_colsum_workspace(int64_t M, int64_t N) {
@@ -415,7 +422,7 @@ extern "C" int mm_colsum(const void* x, float* out, void* workspace, size_t work
         else hipLaunchKernelGGL(colsum_stage1_k<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (float*)workspace, (int)M, (int)N, (long)ld, rpc);
     } else MM_FAIL(MM_ERR_ARG, "colsum: bad dtype %d", dtype);
     MM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_stage2_k, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, (const float*)workspace, out, nchunks, (int)N);
+    hipLaunchKernelGGL(colsum_stage2_k, dim3((unsigned)cdiv(N, 16)), dim3(256), 0, st, (const float*)workspace, out, nchunks, (int)N);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
@@ -528,7 +535,7 @@ extern "C" int mm_relu2_bwd_colsum(const void* h, const void* da, void* dh, floa
         hipLaunchKernelGGL((relu2_bwd_colsum_k<bf16, 8>), dim3((unsigned)cdiv(N, 256), (unsigned)nchunks), dim3(256), 0, st,
                            (const bf16*)h, (const bf16*)da, (bf16*)dh, (float*)workspace, (int)M, (int)N, rpc);
     MM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_stage2_k, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, (const float*)workspace, colsum, nchunks, (int)N);
+    hipLaunchKernelGGL(colsum_stage2_k, dim3((unsigned)cdiv(N, 16)), dim3(256), 0, st, (const float*)workspace, colsum, nchunks, (int)N);
     MM_LAUNCH_CHECK();
     return MM_OK;
 }
