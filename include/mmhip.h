@@ -117,16 +117,6 @@ typedef struct {
 } mm_gemm_args;
 int mm_gemm(const mm_gemm_args* args, void* stream);
 
-/* Weight gradient on the hipBLASLt library, algorithm chosen by measurement: dw[n][k] (f32, row stride ld_dw) =
- * sum_r dy[r][n] * x[r][k], bf16 operands with row strides ld_dy / ld_x.  Replaces the grad_weight GEMM autograd runs for
- * nn.Linear (reference models/decoder.py: every nn.Linear of the decoder block; torch.mm(dy.t(), x) in ATen).  tune = 0: the
- * library heuristic's first algorithm.  tune = 1: the first call for a new (n, k, rows, strides, workspace size) on a device
- * drains the device, times every algorithm of the library that supports the problem within workspace_bytes on `stream`
- * (writing dw each time), keeps the fastest if it beats the heuristic's by more than 2 %, and every later call launches it
- * directly.  Allocates no device memory (workspace may be NULL / 0).  Not for use under stream capture while tuning. */
-int mm_lt_wgrad(const void* dy, const void* x, float* dw, int64_t n, int64_t k, int64_t rows, int64_t ld_dy, int64_t ld_x,
-                int64_t ld_dw, void* workspace, size_t workspace_bytes, int tune, void* stream);
-
 /* column sums: out[n] = sum_m x[m][n] (bias gradients); optional gamma/z terms for LayerScale:
  * replaces the bias-gradient reductions autograd derives from nn.Linear. workspace: see _workspace. */
 size_t mm_colsum_workspace(int64_t M, int64_t N);

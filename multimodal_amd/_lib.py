@@ -51,7 +51,6 @@ _SIGNATURES = {
     "mm_layernorm_bwd": (i32, [vp] * 9 + [vp, sz, i64, i64, i64, i64, i32, vp]),
     "mm_layernorm_bwd_sums": (i32, [vp] * 11 + [vp, sz, i64, i64, i32, vp]),
     "mm_gemm": (i32, [C.POINTER(GemmArgs), vp]),
-    "mm_lt_wgrad": (i32, [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, sz, i32, vp]),
     "mm_colsum_workspace": (sz, [i64, i64]),
     "mm_colsum": (i32, [vp, vp, vp, sz, i64, i64, i64, i32, vp]),
     "mm_colsum_noalloc": (i32, [vp, vp, i64, i64, i64, i32, vp]),

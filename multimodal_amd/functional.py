@@ -568,7 +568,6 @@ def shadows_written(params) -> None:
 
 _DW_SMALL_OWN = os.environ.get("MM_DW_SMALL_OWN", "0") == "1"
 _DW_OWN = os.environ.get("MM_DW_OWN", "0")
-_LT_TUNE = os.environ.get("MM_LT_TUNE", "1")          # "1": sweep, "heur": same call path with the heuristic's pick, "0": torch.mm
 
 
 def _mm_f32(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
@@ -592,11 +591,6 @@ def _mm_f32(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
                         split_k=_split_k(n, k, rows), ws_tag=tag)
     if a.dtype == torch.float32:
         return torch.mm(a, b, out=out) if out is not None else torch.mm(a, b)
-    # the library product with the algorithm picked by a sweep at first sight of the shape (mm_lt_wgrad): the d_model x d_ffn
-    # weight gradients 255 / 245 -> 207 / 210 us against the heuristic's pick.  MM_LT_TUNE=0: torch.mm, the heuristic's pick.
-    if _LT_TUNE != "0" and a.dtype == torch.bfloat16 and b.shape[0] >= 2048 and a.shape[0] * b.shape[1] >= (1 << 20) and \
-            a.stride(0) == 1 and b.stride(1) == 1 and (out is None or out.stride(1) == 1):
-        return ops.lt_wgrad(a.t(), b, out=out, tune=_LT_TUNE == "1")
     if out is not None:
         return torch.mm(a, b, out_dtype=torch.float32, out=out)
     return torch.mm(a, b, out_dtype=torch.float32)

@@ -187,28 +187,6 @@ def layernorm_bwd_sums(x: Tensor, dy: Tensor, dres: Tensor, w: Tensor, mean: Ten
 ACT_NONE, ACT_GELU, ACT_RELU2 = 0, 1, 2
 
 
-_LT_WS_BYTES = 32 << 20
-
-
-def lt_wgrad(dy2: Tensor, x2: Tensor, out: Optional[Tensor] = None, tune: bool = True) -> Tensor:
-    """dW[n][k] = sum_r dy2[r][n] x2[r][k] (bf16 operands, float32 result) on the hipBLASLt library with the algorithm picked by
-    a one-time sweep per shape (mm_lt_wgrad).  dy2 / x2 / out: 2-D, unit stride in the last dim."""
-    if dy2.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16:
-        raise TypeError("lt_wgrad: bfloat16 operands")
-    if dy2.dim() != 2 or x2.dim() != 2 or dy2.shape[0] != x2.shape[0] or dy2.stride(1) != 1 or x2.stride(1) != 1:
-        raise ValueError(f"lt_wgrad: operands {tuple(dy2.shape)}/{dy2.stride()} and {tuple(x2.shape)}/{x2.stride()}")
-    rows, n = dy2.shape
-    k = x2.shape[1]
-    if out is None:
-        out = torch.empty((n, k), dtype=torch.float32, device=x2.device)
-    elif out.dtype != torch.float32 or tuple(out.shape) != (n, k) or out.stride(1) != 1:
-        raise ValueError(f"lt_wgrad: out {tuple(out.shape)}/{out.stride()} {out.dtype}")
-    ws = workspace(_LT_WS_BYTES, x2.device, "lt")          # keyed by the current stream: main and side stream never share it
-    L.check(L.lib().mm_lt_wgrad(L.ptr(dy2), L.ptr(x2), L.ptr(out), n, k, rows, dy2.stride(0), x2.stride(0), out.stride(0),
-                                L.ptr(ws), _LT_WS_BYTES, 1 if tune else 0, L.cur_stream()), "mm_lt_wgrad")
-    return out
-
-
 def gemm(A: Tensor, B: Tensor, M: int, N: int, K: int, *, a_kmajor: bool = False, b_kmajor: bool = False,
          out_dtype=None, bias: Optional[Tensor] = None, pre: Optional[Tensor] = None, mul: Optional[Tensor] = None,
          act: int = ACT_NONE, gamma: Optional[Tensor] = None, rowscale: Optional[Tensor] = None, rows_per_scale: int = 0,
