@@ -624,13 +624,16 @@ def run_extras(a, c, device, world, rank):
         roof["config_batch_latency_us"] = lat["launch_us"]
     log("K1 roofline done; greedy leg")
     greedy = run_leg(extras, "greedy", greedy_bench, device, world, rank)
-    if "error" not in greedy:
-        if world > 1:
-            gt = torch.tensor([greedy["tokens_per_s_per_gpu"]], device=device, dtype=torch.float64)
-            dist.all_reduce(gt, op=dist.ReduceOp.SUM)
-            greedy["tokens_per_s"] = round(float(gt.item()), 1)
-        else:
-            greedy["tokens_per_s"] = greedy["tokens_per_s_per_gpu"]
+    if world > 1:
+        # every rank enters the collective whether or not its own leg failed (a rank that skipped it would hang the others)
+        ok = "error" not in greedy
+        gt = torch.tensor([greedy["tokens_per_s_per_gpu"] if ok else 0.0, 1.0 if ok else 0.0], device=device, dtype=torch.float64)
+        dist.all_reduce(gt, op=dist.ReduceOp.SUM)
+        if ok:
+            greedy["tokens_per_s"] = round(float(gt[0].item()), 1)
+            greedy["ranks_reporting"] = int(gt[1].item())
+    elif "error" not in greedy:
+        greedy["tokens_per_s"] = greedy["tokens_per_s_per_gpu"]
     run_leg(extras, "roofline_mfma", gemm_roofline, device)
     run_leg(extras, "roofline_k2", k2_roofline, device)
     run_leg(extras, "roofline_attn", attn_roofline, device)
