@@ -900,7 +900,8 @@ static BwdPlan plan_bwd(int64_t B, int64_t C, int64_t L, int dtype) {
     if (strip_ok(C, vec) && C / vec >= 16) {
         p.strip = true; p.lpr = (int)(C / vec);
         const int spw = 64 / p.lpr;
-        p.TL = pick_tl(B, L, spw, 8, 64);
+        static const int tlmax = getenv("MM_K1B_TLMAX") ? atoi(getenv("MM_K1B_TLMAX")) : 64;      // A/B knob
+        p.TL = pick_tl(B, L, spw, 8, tlmax);
         p.sps = (int)cdiv(L, p.TL);
         p.nblocks = cdiv(cdiv(B * p.sps, spw), 4);
     } else {
