@@ -344,6 +344,15 @@ __global__ __launch_bounds__(256) void dwconv7_ln_fwd_bcl(const T* __restrict__ 
 // workspace; dwconv7_ln_bwd_reduce adds the rows in a fixed order (deterministic).
 // Workspace row layout: [7][C] dw (tap-major), [C] db, [C] dln_w, [C] dln_b  = 10*C floats.
 // ------------------------------------------------------------------------------------------------
+// The arithmetic is written on explicit pairs of channels (f2_t): the backend issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+// on aligned register pairs directly.  Left to the SLP vectoriser the same loop held 126 v_mov_b32 per 8 rows that only
+// assembled pairs it had chosen across taps, and 80 selects for the zero padding (now done on the packed row before unpacking).
+// Registers: 186 (bf16) / 229 (f32) VGPRs, two waves per SIMD.  A cap at 168 or 128 (three / four waves) makes the compiler spill
+// the rings to scratch inside the loop: 420 us (bf16) and 1570 us (f32) against 231 / 339 at B8192 C64 L250.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ f2_t fma2(f2_t a, f2_t b, f2_t c) { return __builtin_elementwise_fma(a, b, c); }
+static __device__ __forceinline__ f2_t bc2(float s) { return (f2_t){s, s}; }
+
 template <typename T, int VEC, int LPR, int QD, bool HAS_RES>
 __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict__ x, const T* __restrict__ dy,
                                                            const T* __restrict__ dres, const float* __restrict__ w,
@@ -351,13 +360,16 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            T* __restrict__ dx, float* __restrict__ partial,
                                                            int B, int L, int TL, int sps) {
+    static_assert(VEC == 4, "two channel pairs per lane");
     constexpr int SPW = 64 / LPR;
     constexpr int C = VEC * LPR;
+    constexpr int NV = VEC / 2;                  // channel pairs per lane
     constexpr int NP = 10;                       // partial vectors per channel
     constexpr int RING = 8;
     static_assert(RING % QD == 0, "queue depth must divide the ring");
     typedef VecIO<T, VEC> IO;
     typedef typename IO::raw_t raw_t;
+    constexpr int RAWN = sizeof(raw_t) / 4;      // dwords of a packed row piece
     __shared__ float acc_lds[4 * SPW][NP * C];   // 4*SPW strips * 10*C floats = 40 KiB for every (VEC,LPR)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -371,51 +383,75 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
     const int l0 = (int)(strip % sps) * TL;
     const int l1 = min(l0 + TL, L);
     const int c0 = li * VEC;
-    const long rowbase = (long)b * L;
-    const T* xb = x + rowbase * C + c0;
-    const T* dyb = dy + rowbase * C + c0;
-    const T* drb = HAS_RES ? dres + rowbase * C + c0 : nullptr;
-    const float* mub = mean + rowbase;
-    const float* rsb = rstd + rowbase;
-    T* dxb = dx + rowbase * C + c0;
+    // Addresses: a wave-uniform base (the sample of the wave's first strip: scalar registers) plus a 32-bit byte offset per
+    // lane -- the strips of a wave lie in at most SPW + 1 consecutive samples, so the offset always fits.  The loads take the
+    // scalar-base form; per load the lane computes one v_med3 (row clamp) and one multiply-add instead of a 64-bit address
+    // (the 64-bit form cost about 21 vector instructions per row, a sixth of the loop).
+    const int bw = __builtin_amdgcn_readfirstlane(b);
+    const long ubase = (long)bw * L;
+    const char* xu = (const char*)(x + ubase * C);
+    const char* dyu = (const char*)(dy + ubase * C);
+    const char* dru = HAS_RES ? (const char*)(dres + ubase * C) : nullptr;
+    const char* muu = (const char*)(mean + ubase);
+    const char* rsu = (const char*)(rstd + ubase);
+    char* dxu = (char*)(dx + ubase * C);
+    const unsigned relrow = (unsigned)((b - bw) * L);              // rows from the uniform base to this lane's sample
+    const unsigned cbytes = (unsigned)(c0 * sizeof(T));
+    const int Lm1 = L - 1;
+    auto rowof = [&](int l) -> unsigned {                           // clamp into the sample, then rows from the uniform base
+        int r;
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(l), "s"(Lm1));
+        return relrow + (unsigned)r;
+    };
+    auto ldrow = [&](const char* base, unsigned row) -> raw_t {
+        return IO::load_raw_nt((const T*)(base + (row * (unsigned)(C * sizeof(T)) + cbytes)));
+    };
+    auto ldstat = [&](const char* base, unsigned row) -> float { return *(const float*)(base + row * 4u); };
 
-    float wt[7][VEC], bias[VEC], g[VEC];
+    f2_t wt[7][NV], bias[NV], g[NV];
 #pragma unroll
-    for (int v = 0; v < VEC; v++) {
+    for (int v = 0; v < NV; v++) {
 #pragma unroll
-        for (int t = 0; t < 7; t++) wt[t][v] = w[(c0 + v) * 7 + t];
-        bias[v] = cb[c0 + v]; g[v] = lw[c0 + v];
+        for (int t = 0; t < 7; t++) wt[t][v] = (f2_t){w[(c0 + 2 * v) * 7 + t], w[(c0 + 2 * v + 1) * 7 + t]};
+        bias[v] = (f2_t){cb[c0 + 2 * v], cb[c0 + 2 * v + 1]};
+        g[v] = (f2_t){lw[c0 + 2 * v], lw[c0 + 2 * v + 1]};
     }
-    float pdw[7][VEC], pdb[VEC], pdg[VEC], pdbeta[VEC];
+    f2_t pdw[7][NV], pdb[NV], pdg[NV], pdbeta[NV];
 #pragma unroll
-    for (int v = 0; v < VEC; v++) {
+    for (int v = 0; v < NV; v++) {
 #pragma unroll
-        for (int t = 0; t < 7; t++) pdw[t][v] = 0.f;
-        pdb[v] = 0.f; pdg[v] = 0.f; pdbeta[v] = 0.f;
+        for (int t = 0; t < 7; t++) pdw[t][v] = bc2(0.f);
+        pdb[v] = bc2(0.f); pdg[v] = bc2(0.f); pdbeta[v] = bc2(0.f);
     }
     // Row pipeline as in the forward kernel: no branch guards a load.  Row indices are clamped into the sample, rows
     // outside it are zeroed by selects when they are consumed; x, dy, (mean, rstd) and dres each keep QD rows in flight.
-    auto clampl = [&](int l) -> long { return (long)min(max(l, 0), L - 1); };
-    auto enter = [&](raw_t r, bool pad, float (&dst)[VEC]) {
-        IO::unpack(r, dst);
+    auto widen = [&](raw_t r, f2_t (&dst)[NV]) {
+        float tmp[VEC];
+        IO::unpack(r, tmp);
 #pragma unroll
-        for (int v = 0; v < VEC; v++) dst[v] = pad ? 0.f : dst[v];
+        for (int v = 0; v < NV; v++) dst[v] = (f2_t){tmp[2 * v], tmp[2 * v + 1]};
     };
-    float xw[RING][VEC], dc[RING][VEC];
+    auto enter = [&](raw_t r, bool pad, f2_t (&dst)[NV]) {          // zero padding on the packed row: all-zero bits are 0.0
+#pragma unroll
+        for (int k = 0; k < RAWN; k++) r[k] = pad ? decltype(r[k] + 0)(0) : r[k];
+        widen(r, dst);
+    };
+    f2_t xw[RING][NV], dc[RING][NV];
     raw_t qx[QD], qdy[QD], qdr[QD];
     float qmu[QD], qrs[QD];
     const int lw0 = l0 - 3;                      // first row of the walk
     {
         raw_t head[6];
 #pragma unroll
-        for (int s = 0; s < 6; s++) head[s] = IO::load_raw_nt(xb + clampl(lw0 - 3 + s) * C);        // rows l0-6 .. l0-1
+        for (int s = 0; s < 6; s++) head[s] = ldrow(xu, rowof(lw0 - 3 + s));                         // rows l0-6 .. l0-1
 #pragma unroll
         for (int s = 0; s < QD; s++) {
-            qx[s] = IO::load_raw_nt(xb + clampl(lw0 + 3 + s) * C);
-            qdy[s] = IO::load_raw_nt(dyb + clampl(lw0 + s) * C);
-            qmu[s] = mub[clampl(lw0 + s)];
-            qrs[s] = rsb[clampl(lw0 + s)];
-            if (HAS_RES) qdr[s] = IO::load_raw_nt(drb + clampl(lw0 - 3 + s) * C);
+            qx[s] = ldrow(xu, rowof(lw0 + 3 + s));
+            const unsigned rdy = rowof(lw0 + s);
+            qdy[s] = ldrow(dyu, rdy);
+            qmu[s] = ldstat(muu, rdy);
+            qrs[s] = ldstat(rsu, rdy);
+            if (HAS_RES) qdr[s] = ldrow(dru, rowof(lw0 - 3 + s));
         }
 #pragma unroll
         for (int s = 0; s < 6; s++) { const int r = lw0 - 3 + s; enter(head[s], (r < 0) | (r >= L), xw[s]); }
@@ -423,7 +459,7 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
 #pragma unroll
     for (int s = 0; s < RING; s++)
 #pragma unroll
-        for (int v = 0; v < VEC; v++) dc[s][v] = 0.f;
+        for (int v = 0; v < NV; v++) dc[s][v] = bc2(0.f);
 
     const float invC = 1.0f / (float)C;
     const int lend = l1 + 3;
@@ -433,74 +469,78 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
             const int l = base + i;                         // row whose dconv is produced now
             const int k = i % QD;
             enter(qx[k], (l + 3 < 0) | (l + 3 >= L), xw[(i + 6) % RING]);      // row l+3 completes the window of row l
-            qx[k] = IO::load_raw_nt(xb + clampl(l + 3 + QD) * C);
+            qx[k] = ldrow(xu, rowof(l + 3 + QD));
             // rows outside the image are computed on zeros (mu = rs = 0 -> dconv = 0): control flow stays
             // uniform, so the DPP sums always run with full EXEC
             const bool inrow = (l >= 0) & (l < L) & (l < lend);
-            float gy[VEC], xh[VEC], gg[VEC], d[VEC];
+            f2_t gy[NV], xh[NV], gg[NV], d[NV];
             enter(qdy[k], !inrow, gy);
             const float mu = inrow ? qmu[k] : 0.f, rs = inrow ? qrs[k] : 0.f;
-            qdy[k] = IO::load_raw_nt(dyb + clampl(l + QD) * C);
-            qmu[k] = mub[clampl(l + QD)];
-            qrs[k] = rsb[clampl(l + QD)];
-            float s1 = 0.f, s2 = 0.f;
+            const unsigned rdy = rowof(l + QD);
+            qdy[k] = ldrow(dyu, rdy);
+            qmu[k] = ldstat(muu, rdy);
+            qrs[k] = ldstat(rsu, rdy);
 #pragma unroll
-            for (int v = 0; v < VEC; v++) {
-                float a = bias[v];
+            for (int v = 0; v < NV; v++) {
+                f2_t a = bias[v];
 #pragma unroll
-                for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], xw[(i + t) % RING][v], a);
-                xh[v] = (a - mu) * rs;
+                for (int t = 0; t < 7; t++) a = fma2(wt[t][v], xw[(i + t) % RING][v], a);
+                xh[v] = (a - bc2(mu)) * bc2(rs);
                 gg[v] = gy[v] * g[v];
-                s1 += gg[v]; s2 = fmaf(gg[v], xh[v], s2);
             }
-            const float m1 = group_sum<LPR>(s1) * invC;
-            const float m2 = group_sum<LPR>(s2) * invC;
+            // the lane's 4 terms of each row sum: pairs first, then the two halves
+            const f2_t p1 = gg[0] + gg[1];
+            const f2_t p2 = fma2(gg[1], xh[1], gg[0] * xh[0]);
+            const float m1 = group_sum<LPR>(p1.x + p1.y) * invC;
+            const float m2 = group_sum<LPR>(p2.x + p2.y) * invC;
 #pragma unroll
-            for (int v = 0; v < VEC; v++) d[v] = rs * (gg[v] - m1 - xh[v] * m2);
+            for (int v = 0; v < NV; v++) d[v] = bc2(rs) * ((gg[v] - bc2(m1)) - xh[v] * bc2(m2));
             if (l >= l0 && l < l1) {
 #pragma unroll
-                for (int v = 0; v < VEC; v++) {
-                    pdg[v] = fmaf(gy[v], xh[v], pdg[v]);
+                for (int v = 0; v < NV; v++) {
+                    pdg[v] = fma2(gy[v], xh[v], pdg[v]);
                     pdbeta[v] += gy[v];
                     pdb[v] += d[v];
 #pragma unroll
-                    for (int t = 0; t < 7; t++) pdw[t][v] = fmaf(d[v], xw[(i + t) % RING][v], pdw[t][v]);
+                    for (int t = 0; t < 7; t++) pdw[t][v] = fma2(d[v], xw[(i + t) % RING][v], pdw[t][v]);
                 }
             }
 #pragma unroll
-            for (int v = 0; v < VEC; v++) dc[i][v] = d[v];  // dconv ring slot of row l is i (RING == unroll)
+            for (int v = 0; v < NV; v++) dc[i][v] = d[v];  // dconv ring slot of row l is i (RING == unroll)
             // dx(l-3) = sum_t w[t] * dconv(l-3-t+3) = sum_t w[t] * dconv(l-t)
             const int lo = l - 3;
-            float o[VEC];
+            f2_t o[NV];
             if (HAS_RES) {
-                IO::unpack(qdr[k], o);
-                qdr[k] = IO::load_raw_nt(drb + clampl(lo + QD) * C);
+                widen(qdr[k], o);
+                qdr[k] = ldrow(dru, rowof(lo + QD));
             } else {
 #pragma unroll
-                for (int v = 0; v < VEC; v++) o[v] = 0.f;
+                for (int v = 0; v < NV; v++) o[v] = bc2(0.f);
             }
             if (live && lo >= l0 && lo < l1) {
 #pragma unroll
-                for (int v = 0; v < VEC; v++) {
-                    float a = o[v];
+                for (int v = 0; v < NV; v++) {
+                    f2_t a = o[v];
 #pragma unroll
-                    for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], dc[(i - t + RING) % RING][v], a);
+                    for (int t = 0; t < 7; t++) a = fma2(wt[t][v], dc[(i - t + RING) % RING][v], a);
                     o[v] = a;
                 }
-                IO::store_nt(dxb + (long)lo * C, o);
+                const float of[VEC] = {o[0].x, o[0].y, o[1].x, o[1].y};
+                IO::store_nt((T*)(dxu + ((relrow + (unsigned)lo) * (unsigned)(C * sizeof(T)) + cbytes)), of);
             }
         }
     }
     // ---- block-level sum of the parameter partials
     float* mine = acc_lds[wave * SPW + sub];
+    const float z = live ? 1.f : 0.f;
 #pragma unroll
-    for (int v = 0; v < VEC; v++) {
-        const float z = live ? 1.f : 0.f;
+    for (int v = 0; v < NV; v++) {
+        const int c = c0 + 2 * v;
 #pragma unroll
-        for (int t = 0; t < 7; t++) mine[t * C + c0 + v] = pdw[t][v] * z;
-        mine[7 * C + c0 + v] = pdb[v] * z;
-        mine[8 * C + c0 + v] = pdg[v] * z;
-        mine[9 * C + c0 + v] = pdbeta[v] * z;
+        for (int t = 0; t < 7; t++) { mine[t * C + c] = pdw[t][v].x * z; mine[t * C + c + 1] = pdw[t][v].y * z; }
+        mine[7 * C + c] = pdb[v].x * z; mine[7 * C + c + 1] = pdb[v].y * z;
+        mine[8 * C + c] = pdg[v].x * z; mine[8 * C + c + 1] = pdg[v].y * z;
+        mine[9 * C + c] = pdbeta[v].x * z; mine[9 * C + c + 1] = pdbeta[v].y * z;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < NP * C; idx += 256) {
@@ -900,7 +940,10 @@ static BwdPlan plan_bwd(int64_t B, int64_t C, int64_t L, int dtype) {
     if (strip_ok(C, vec) && C / vec >= 16) {
         p.strip = true; p.lpr = (int)(C / vec);
         const int spw = 64 / p.lpr;
-        static const int tlmax = getenv("MM_K1B_TLMAX") ? atoi(getenv("MM_K1B_TLMAX")) : 64;      // A/B knob
+        // strip length cap: 64 rows in f32; 128 in bf16, where the 12 halo rows of x and 6 of dy a strip re-reads cost
+        // relatively more (B8192 C64 L250: 231 -> 214 us; f32: 339 either way).  Shorter strips lose in both (32: 294 / 374 us).
+        static const int tlmax_env = getenv("MM_K1B_TLMAX") ? atoi(getenv("MM_K1B_TLMAX")) : 0;   // A/B knob
+        const int tlmax = tlmax_env > 0 ? tlmax_env : (dtype == MM_BF16 ? 128 : 64);
         p.TL = pick_tl(B, L, spw, 8, tlmax);
         p.sps = (int)cdiv(L, p.TL);
         p.nblocks = cdiv(cdiv(B * p.sps, spw), 4);
@@ -910,7 +953,6 @@ static BwdPlan plan_bwd(int64_t B, int64_t C, int64_t L, int dtype) {
         p.sps = (int)cdiv(L, p.TL);
         p.nblocks = B * p.sps;
     }
-    (void)dtype;
     return p;
 }
 
