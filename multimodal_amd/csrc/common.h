@@ -140,7 +140,11 @@ template <> struct VecIO<bf16, 1> {
 // this form the compiler folds the move into the add that follows it (v_add_f32_dpp: one instruction for two -- the strip K1b
 // loop held 64 separate v_mov_b32_dpp per 8 rows)
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+#ifdef MM_DPP_PLAIN_MOV          // A/B: the separate-move form (benchmarks/build_variant.sh plainmov dwconv_ln -DMM_DPP_PLAIN_MOV)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+#else
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+#endif
 }
 // Sum over aligned groups of G consecutive lanes (G in 1,2,4,8,16,32,64); every lane of the group gets the sum.
 // All 64 lanes must be active.

@@ -562,11 +562,12 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          T* __restrict__ dx, float* __restrict__ partial,
                                                          int B, int C, int L, int TL, int sps) {
-    constexpr int VEC = 4, RING = 8, R = 2, NW = NT / 64;   // R = 2: a row's x window (7 rows) must still be in the 8-slot ring
-                                                              // when the group is finished (weight gradient)
+    constexpr int VEC = 4, NV = 2, RING = 8, R = 2, NW = NT / 64;   // R = 2: a row's x window (7 rows) must still be in the 8-slot
+                                                                      // ring when the group is finished (weight gradient)
     static_assert(RING % QD == 0 && NW <= 8, "queue depth must divide the ring; at most 8 waves");
     typedef VecIO<T, VEC> IO;
     typedef typename IO::raw_t raw_t;
+    constexpr int RAWN = sizeof(raw_t) / 4;
     __shared__ __attribute__((aligned(16))) float red[2][NW][4];         // [parity of the group][wave][s1 row0, s1 row1, s2 row0, s2 row1]
     const int b = blockIdx.x / sps;
     const int l0 = (blockIdx.x % sps) * TL;
@@ -575,7 +576,8 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
     const long rowbase = (long)b * L;
     const int c = threadIdx.x * VEC;
     const bool cok = c < C;
-    const int cidx = cok ? c : 0;                 // idle threads shadow chunk 0 (valid addresses), contribute nothing
+    const int cidx = cok ? c : 0;                 // idle threads shadow chunk 0 (valid addresses and finite values); what they
+                                                  // compute is never stored and is masked out of the row sums
     // row addresses are uniform (scalar registers); the only per-thread part is the 32-bit channel offset cidx
     const T* xb = x + rowbase * C;
     const T* dyb = dy + rowbase * C;
@@ -585,31 +587,37 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
     const float* rsb = rstd + rowbase;
     const float invC = 1.0f / (float)C;
 
-    float wt[7][VEC], bias[VEC], g[VEC];
+    // arithmetic on explicit channel pairs (see the strip kernel)
+    f2_t wt[7][NV], bias[NV], g[NV];
 #pragma unroll
-    for (int v = 0; v < VEC; v++)
+    for (int v = 0; v < NV; v++) {
 #pragma unroll
-        for (int t = 0; t < 7; t++) wt[t][v] = w[(cidx + v) * 7 + t];
-    IO_f4(cb + cidx, bias);
-    IO_f4(lw + cidx, g);
-    // The 10 parameter-gradient partial vectors of this thread's 4 channels live in LDS (thread-private float4 slots, no
+        for (int t = 0; t < 7; t++) wt[t][v] = (f2_t){w[(cidx + 2 * v) * 7 + t], w[(cidx + 2 * v + 1) * 7 + t]};
+        bias[v] = (f2_t){cb[cidx + 2 * v], cb[cidx + 2 * v + 1]};
+        g[v] = (f2_t){lw[cidx + 2 * v], lw[cidx + 2 * v + 1]};
+    }
+    // The 10 parameter-gradient partial vectors of this thread's 4 channels live in LDS (thread-private 16-byte slots, no
     // synchronisation): in registers (40 of them) the kernel exceeds 256 VGPRs at 8 waves per workgroup, and the spill
     // reloads the compiler then places in the loop each wait for ALL outstanding loads (vmcnt(0)), undoing the prefetch.
-    extern __shared__ __attribute__((aligned(16))) float4 part[];        // [10][NT]: dw taps 0..6, db, dln_w, dln_b
-    auto padd = [&](int which, const float (&a)[VEC]) {
-        float4 t = part[which * NT + threadIdx.x];
-        t.x += a[0]; t.y += a[1]; t.z += a[2]; t.w += a[3];
-        part[which * NT + threadIdx.x] = t;
+    extern __shared__ __attribute__((aligned(16))) mm_f4_t part[];       // [10][NT]: dw taps 0..6, db, dln_w, dln_b
+    auto padd = [&](int which, const f2_t (&a)[NV]) {
+        part[which * NT + threadIdx.x] += __builtin_shufflevector(a[0], a[1], 0, 1, 2, 3);
     };
 #pragma unroll
-    for (int j = 0; j < 10; j++) part[j * NT + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < 10; j++) part[j * NT + threadIdx.x] = (mm_f4_t){0.f, 0.f, 0.f, 0.f};
     auto clampl = [&](int l) -> long { return (long)min(max(l, 0), L - 1); };
-    auto enter = [&](raw_t r, bool pad, float (&dst)[VEC]) {
-        IO::unpack(r, dst);
+    auto widen = [&](raw_t r, f2_t (&dst)[NV]) {
+        float tmp[VEC];
+        IO::unpack(r, tmp);
 #pragma unroll
-        for (int v = 0; v < VEC; v++) dst[v] = pad ? 0.f : dst[v];
+        for (int v = 0; v < NV; v++) dst[v] = (f2_t){tmp[2 * v], tmp[2 * v + 1]};
     };
-    float xw[RING][VEC], dc[RING][VEC];
+    auto enter = [&](raw_t r, bool pad, f2_t (&dst)[NV]) {          // zero padding on the packed row (pad is uniform)
+#pragma unroll
+        for (int k = 0; k < RAWN; k++) r[k] = pad ? decltype(r[k] + 0)(0) : r[k];
+        widen(r, dst);
+    };
+    f2_t xw[RING][NV], dc[RING][NV];
     raw_t qx[QD], qdy[QD], qdr[QD];
     float qmu[QD], qrs[QD];                      // uniform (scalar loads), fetched QD rows ahead like the rest
     const int lw0 = l0 - 3;                      // first row of the walk
@@ -631,11 +639,12 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
 #pragma unroll
     for (int s = 0; s < RING; s++)
 #pragma unroll
-        for (int v = 0; v < VEC; v++) dc[s][v] = 0.f;
+        for (int v = 0; v < NV; v++) dc[s][v] = bc2(0.f);
 
     const int lend = l1 + 3;
-    float gg[R][VEC], xh[R][VEC], ores[R][VEC], rsr[R];
-    float acc8[VEC], acc9[VEC];
+    f2_t gg[R][NV], xh[R][NV], ores[R][NV];
+    float rsr[R];
+    f2_t acc8[NV], acc9[NV];
     int grp = 0;
     for (int base = lw0; base < lend; base += RING) {
 #pragma unroll
@@ -645,15 +654,15 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
             enter(qx[k], (l + 3 < 0) | (l + 3 >= L), xw[(i + 6) % RING]);
             qx[k] = IO::load_raw_nt(xb + clampl(l + 3 + QD) * C + cidx);
             const bool inrow = (l >= 0) & (l < L) & (l < lend);          // uniform
-            float gy[VEC];
+            f2_t gy[NV];
             enter(qdy[k], !inrow, gy);
             qdy[k] = IO::load_raw_nt(dyb + clampl(l + QD) * C + cidx);
             if (HAS_RES) {
-                IO::unpack(qdr[k], ores[r]);                             // dres of row l-3 (used if that row is ours)
+                widen(qdr[k], ores[r]);                                  // dres of row l-3 (used if that row is ours)
                 qdr[k] = IO::load_raw_nt(drb + clampl(l - 3 + QD) * C + cidx);
             } else {
 #pragma unroll
-                for (int v = 0; v < VEC; v++) ores[r][v] = 0.f;
+                for (int v = 0; v < NV; v++) ores[r][v] = bc2(0.f);
             }
             __builtin_amdgcn_sched_barrier(0);    // keep the loads here: the scheduler would sink them to their use
             const float mu = inrow ? qmu[k] : 0.f;
@@ -661,37 +670,37 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
             qmu[k] = mub[clampl(l + QD)];                                // uniform address: scalar loads
             qrs[k] = rsb[clampl(l + QD)];
             rsr[r] = rs;
-            const bool own = (l >= l0) & (l < l1);
+            const bool own = (l >= l0) & (l < l1);                       // uniform
 #pragma unroll
-            for (int v = 0; v < VEC; v++) {
-                float a = bias[v];
+            for (int v = 0; v < NV; v++) {
+                f2_t a = bias[v];
 #pragma unroll
-                for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], xw[(i + t) % RING][v], a);
-                xh[r][v] = (a - mu) * rs;
+                for (int t = 0; t < 7; t++) a = fma2(wt[t][v], xw[(i + t) % RING][v], a);
+                xh[r][v] = (a - bc2(mu)) * bc2(rs);
                 gg[r][v] = gy[v] * g[v];
             }
             // parameter-gradient terms of the group's rows are summed in registers and added to the LDS partials ONCE per
             // group: a read-modify-write of all 10 partial vectors per row made the LDS stores the bottleneck (1.3k cycles
             // per row and workgroup: 0.25 of HBM on the wide shapes)
-            if (r == 0) {
+            {   // rows outside [l0, l1) contribute nothing: dy scaled by a uniform 0 / 1 (one multiply per pair, no selects, no
+                // branch whose join would cost register copies)
+                const float ow = own ? 1.f : 0.f;
 #pragma unroll
-                for (int v = 0; v < VEC; v++) { acc8[v] = 0.f; acc9[v] = 0.f; }
-            }
-#pragma unroll
-            for (int v = 0; v < VEC; v++) {
-                acc8[v] = own ? fmaf(gy[v], xh[r][v], acc8[v]) : acc8[v];
-                acc9[v] = own ? acc9[v] + gy[v] : acc9[v];
+                for (int v = 0; v < NV; v++) {
+                    const f2_t gyo = gy[v] * bc2(ow);
+                    if (r == 0) { acc8[v] = gyo * xh[r][v]; acc9[v] = gyo; }
+                    else { acc8[v] = fma2(gyo, xh[r][v], acc8[v]); acc9[v] += gyo; }
+                }
             }
             if (r != R - 1) continue;
             // ---- the group's 2 rows: both row sums with one barrier
             float s1[R], s2[R];
 #pragma unroll
             for (int rr = 0; rr < R; rr++) {
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int v = 0; v < VEC; v++) { t1 += gg[rr][v]; t2 = fmaf(gg[rr][v], xh[rr][v], t2); }
-                s1[rr] = wave_sum_u(cok ? t1 : 0.f);
-                s2[rr] = wave_sum_u(cok ? t2 : 0.f);
+                const f2_t p1 = gg[rr][0] + gg[rr][1];
+                const f2_t p2 = fma2(gg[rr][1], xh[rr][1], gg[rr][0] * xh[rr][0]);
+                s1[rr] = wave_sum_u(cok ? p1.x + p1.y : 0.f);
+                s2[rr] = wave_sum_u(cok ? p2.x + p2.y : 0.f);
             }
             const int par = grp & 1;
             grp++;
@@ -706,25 +715,22 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
             for (int rr = 0; rr < R; rr++) {
                 const int ii = i - (R - 1) + rr;            // unroll index of this row (static)
                 const int lr = l - (R - 1) + rr;
-                const bool ownr = (lr >= l0) & (lr < l1);
-                float d[VEC];
 #pragma unroll
-                for (int v = 0; v < VEC; v++) {
-                    d[v] = cok ? rsr[rr] * (gg[rr][v] - m1[rr] - xh[rr][v] * m2[rr]) : 0.f;
-                    dc[ii][v] = d[v];                       // dconv ring slot of row lr is ii (RING == unroll)
-                }
+                for (int v = 0; v < NV; v++)                // dconv ring slot of row lr is ii (RING == unroll)
+                    dc[ii][v] = bc2(rsr[rr]) * ((gg[rr][v] - bc2(m1[rr])) - xh[rr][v] * bc2(m2[rr]));
                 // dx(lr-3) = sum_t w[t] * dconv(lr-t)
                 const int lo = lr - 3;
                 if (cok && lo >= l0 && lo < l1) {
-                    float o[VEC];
+                    f2_t o[NV];
 #pragma unroll
-                    for (int v = 0; v < VEC; v++) {
-                        float a = ores[rr][v];
+                    for (int v = 0; v < NV; v++) {
+                        f2_t a = ores[rr][v];
 #pragma unroll
-                        for (int t = 0; t < 7; t++) a = fmaf(wt[t][v], dc[(ii - t + RING) % RING][v], a);
+                        for (int t = 0; t < 7; t++) a = fma2(wt[t][v], dc[(ii - t + RING) % RING][v], a);
                         o[v] = a;
                     }
-                    IO::store_nt(dxb + (long)lo * C + cidx, o);
+                    const float of[VEC] = {o[0].x, o[0].y, o[1].x, o[1].y};
+                    IO::store_nt(dxb + (long)lo * C + cidx, of);
                 }
             }
             {   // both rows' parameter terms (rows outside [l0, l1) contribute nothing), one LDS update per partial vector
@@ -732,14 +738,14 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
                 const int la = l - 1, lb = l;
                 const float oa = ((la >= l0) & (la < l1)) ? 1.f : 0.f, ob = ((lb >= l0) & (lb < l1)) ? 1.f : 0.f;   // uniform
                 if (oa + ob > 0.f) {
-                    float da[VEC], db_[VEC], acc[VEC];
+                    f2_t da[NV], db_[NV], acc[NV];
 #pragma unroll
-                    for (int v = 0; v < VEC; v++) { da[v] = oa * dc[i0][v]; db_[v] = ob * dc[i1][v]; acc[v] = da[v] + db_[v]; }
+                    for (int v = 0; v < NV; v++) { da[v] = bc2(oa) * dc[i0][v]; db_[v] = bc2(ob) * dc[i1][v]; acc[v] = da[v] + db_[v]; }
                     padd(7, acc);
 #pragma unroll
                     for (int t = 0; t < 7; t++) {
 #pragma unroll
-                        for (int v = 0; v < VEC; v++) acc[v] = fmaf(da[v], xw[(i0 + t) % RING][v], db_[v] * xw[(i1 + t) % RING][v]);
+                        for (int v = 0; v < NV; v++) acc[v] = fma2(da[v], xw[(i0 + t) % RING][v], db_[v] * xw[(i1 + t) % RING][v]);
                         padd(t, acc);
                     }
                     padd(8, acc8);
@@ -751,7 +757,7 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
     if (cok) {
         float* prow = partial + (long)blockIdx.x * 10 * C;
 #pragma unroll
-        for (int j = 0; j < 10; j++) *reinterpret_cast<float4*>(prow + j * C + c) = part[j * NT + threadIdx.x];
+        for (int j = 0; j < 10; j++) *reinterpret_cast<mm_f4_t*>(prow + j * C + c) = part[j * NT + threadIdx.x];
     }
 }
 
