@@ -555,6 +555,9 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
 // the strip kernel (register rings for x and dconv, QD packed rows of x / dy / dres in flight, no guarded loads).  The two
 // LayerNorm-backward row sums are independent of each other, so a group of R = 4 rows needs ONE barrier: per-wave sums
 // (DPP, wave-uniform) -> LDS -> 3 DPP steps over the first NW lanes.  mean/rstd of a row are uniform: scalar loads.
+#ifndef K1W_PREG
+#define K1W_PREG 2
+#endif
 template <typename T, int NT, int QD, bool HAS_RES>
 __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const T* __restrict__ dres, const float* __restrict__ w,
@@ -596,15 +599,33 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
         bias[v] = (f2_t){cb[cidx + 2 * v], cb[cidx + 2 * v + 1]};
         g[v] = (f2_t){lw[cidx + 2 * v], lw[cidx + 2 * v + 1]};
     }
-    // The 10 parameter-gradient partial vectors of this thread's 4 channels live in LDS (thread-private 16-byte slots, no
-    // synchronisation): in registers (40 of them) the kernel exceeds 256 VGPRs at 8 waves per workgroup, and the spill
-    // reloads the compiler then places in the loop each wait for ALL outstanding loads (vmcnt(0)), undoing the prefetch.
+    // The 10 parameter-gradient partial vectors of this thread's 4 channels.  Until round 3 they had to live in LDS (thread-private
+    // 16-byte slots, no synchronisation): in registers (40 of them) the SLP-paired kernel exceeded 256 VGPRs at 8 waves per
+    // workgroup, and the spill reloads the compiler then placed in the loop each waited for ALL outstanding loads (vmcnt(0)).
+    // PREG (the build default, K1W_PREG = 2): since the pair-arithmetic rewrite the kernel needs 152 (bf16) / 190 (f32) VGPRs, so the
+    // partials fit in registers again (186-196 / 224-242, no spills) and the LDS read-modify-write -- 11 KB per wave and row, a
+    // quarter of a row's time -- is gone: 338 -> 307 us (bf16), 348 -> 331 us (f32) at B2048 C1600 L31.  K1W_PREG = 0 keeps the LDS
+    // slots (1: bf16 only in registers).
+    constexpr bool PREG = K1W_PREG && (sizeof(T) == 2 || K1W_PREG == 2);
     extern __shared__ __attribute__((aligned(16))) mm_f4_t part[];       // [10][NT]: dw taps 0..6, db, dln_w, dln_b
+    f2_t preg[PREG ? 10 : 1][NV];
     auto padd = [&](int which, const f2_t (&a)[NV]) {
-        part[which * NT + threadIdx.x] += __builtin_shufflevector(a[0], a[1], 0, 1, 2, 3);
-    };
+        if constexpr (PREG) {
 #pragma unroll
-    for (int j = 0; j < 10; j++) part[j * NT + threadIdx.x] = (mm_f4_t){0.f, 0.f, 0.f, 0.f};
+            for (int v = 0; v < NV; v++) preg[which][v] += a[v];
+        } else {
+            part[which * NT + threadIdx.x] += __builtin_shufflevector(a[0], a[1], 0, 1, 2, 3);
+        }
+    };
+    if constexpr (PREG) {
+#pragma unroll
+        for (int j = 0; j < 10; j++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) preg[j][v] = bc2(0.f);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 10; j++) part[j * NT + threadIdx.x] = (mm_f4_t){0.f, 0.f, 0.f, 0.f};
+    }
     auto clampl = [&](int l) -> long { return (long)min(max(l, 0), L - 1); };
     auto widen = [&](raw_t r, f2_t (&dst)[NV]) {
         float tmp[VEC];
@@ -757,7 +778,10 @@ __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ 
     if (cok) {
         float* prow = partial + (long)blockIdx.x * 10 * C;
 #pragma unroll
-        for (int j = 0; j < 10; j++) *reinterpret_cast<mm_f4_t*>(prow + j * C + c) = part[j * NT + threadIdx.x];
+        for (int j = 0; j < 10; j++) {
+            if constexpr (PREG) *reinterpret_cast<mm_f4_t*>(prow + j * C + c) = __builtin_shufflevector(preg[j][0], preg[j][1], 0, 1, 2, 3);
+            else *reinterpret_cast<mm_f4_t*>(prow + j * C + c) = part[j * NT + threadIdx.x];
+        }
     }
 }
 
@@ -992,7 +1016,7 @@ static int launch_bwd(const BwdPlan& p, const void* x, const void* dy, const voi
     } else {
         MM_CHECK(C % 4 == 0 && C <= 2048, "dwconv7_ln_bwd: C=%lld unsupported (need C %% 4 == 0 and C <= 2048)", (long long)C);
 #define LAUNCH_W(NT_, RES_) do { \
-            const size_t lds_ = (size_t)10 * NT_ * sizeof(float4); \
+            const size_t lds_ = (K1W_PREG && (sizeof(T) == 2 || K1W_PREG == 2)) ? 0 : (size_t)10 * NT_ * sizeof(float4);   /* bf16: partials in registers */ \
             static bool attr_ = false;                 /* 80 KiB at NT = 512: above the default dynamic-LDS limit */ \
             if (!attr_) { (void)hipFuncSetAttribute((const void*)dwconv7_ln_bwd_wide<T, NT_, 2, RES_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); attr_ = true; } \
             hipLaunchKernelGGL((dwconv7_ln_bwd_wide<T, NT_, 2, RES_>), grid, dim3(NT_), lds_, st, (const T*)x, (const T*)dy, \
