@@ -558,6 +558,10 @@ __global__ __launch_bounds__(256) void dwconv7_ln_bwd_strip(const T* __restrict_
 #ifndef K1W_PREG
 #define K1W_PREG 2
 #endif
+#ifndef K1W_QD_BF16
+#define K1W_QD_BF16 4          // rows in flight per tensor: a row step of the wide kernel takes about 1 us, HBM latency under load more
+#endif
+#define K1W_QD(T) (sizeof(T) == 2 ? K1W_QD_BF16 : 2)
 template <typename T, int NT, int QD, bool HAS_RES>
 __global__ __launch_bounds__(NT) void dwconv7_ln_bwd_wide(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const T* __restrict__ dres, const float* __restrict__ w,
@@ -1018,8 +1022,8 @@ static int launch_bwd(const BwdPlan& p, const void* x, const void* dy, const voi
 #define LAUNCH_W(NT_, RES_) do { \
             const size_t lds_ = (K1W_PREG && (sizeof(T) == 2 || K1W_PREG == 2)) ? 0 : (size_t)10 * NT_ * sizeof(float4);   /* bf16: partials in registers */ \
             static bool attr_ = false;                 /* 80 KiB at NT = 512: above the default dynamic-LDS limit */ \
-            if (!attr_) { (void)hipFuncSetAttribute((const void*)dwconv7_ln_bwd_wide<T, NT_, 2, RES_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); attr_ = true; } \
-            hipLaunchKernelGGL((dwconv7_ln_bwd_wide<T, NT_, 2, RES_>), grid, dim3(NT_), lds_, st, (const T*)x, (const T*)dy, \
+            if (!attr_) { (void)hipFuncSetAttribute((const void*)dwconv7_ln_bwd_wide<T, NT_, K1W_QD(T), RES_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); attr_ = true; } \
+            hipLaunchKernelGGL((dwconv7_ln_bwd_wide<T, NT_, K1W_QD(T), RES_>), grid, dim3(NT_), lds_, st, (const T*)x, (const T*)dy, \
                                (const T*)dres, w, b, lw, mean, rstd, (T*)dx, partial, (int)B, (int)C, (int)L, p.TL, p.sps); } while (0)
         if (C <= 1024) { if (dres) LAUNCH_W(256, true); else LAUNCH_W(256, false); }
         else { if (dres) LAUNCH_W(512, true); else LAUNCH_W(512, false); }
