@@ -971,7 +971,11 @@ static BwdPlan plan_bwd(int64_t B, int64_t C, int64_t L, int dtype) {
     BwdPlan p{};
     const int vec = 4;   // both dtypes use VEC=4 in backward (register budget: two rings + 10 partial vectors)
     p.vec = vec;
-    if (strip_ok(C, vec) && C / vec >= 16) {
+    // the strip kernel addresses a wave's rows by 32-bit byte offsets from the wave's first sample: its strips lie in at most
+    // spw + 1 consecutive samples, which must span less than 4 GiB (L < 500 000 at C = 256 in f32); longer samples take the wide kernel
+    const bool lanes_ok = strip_ok(C, vec) && C / vec >= 16;
+    const bool fits32 = lanes_ok && (64 / (C / vec) + 1) * L * C * (int64_t)4 < ((int64_t)1 << 32);   // same for both dtypes: one plan
+    if (lanes_ok && fits32) {
         p.strip = true; p.lpr = (int)(C / vec);
         const int spw = 64 / p.lpr;
         // strip length cap: 64 rows in f32; 128 in bf16, where the 12 halo rows of x and 6 of dy a strip re-reads cost
