@@ -9,7 +9,10 @@ from multimodal_amd import ops
 dev = torch.device("cuda:0")
 B = int(os.environ.get("BATCH", "1024"))
 lib = os.environ.get("LIB") == "1"
-for (C, Ln) in [(64, 250), (128, 125), (256, 62), (512, 31)]:
+stages = [(64, 250), (128, 125), (256, 62), (512, 31)]
+if os.environ.get("STAGES"):                       # e.g. STAGES=1600:31 (the headline config's last stage)
+    stages = [tuple(int(v) for v in st.split(":")) for st in os.environ["STAGES"].split(",")]
+for (C, Ln) in stages:
     M = B * Ln
     xn = torch.randn(M, C, device=dev).to(torch.bfloat16)
     x = torch.randn(M, C, device=dev).to(torch.bfloat16)

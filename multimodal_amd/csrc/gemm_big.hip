@@ -162,10 +162,10 @@ __device__ __forceinline__ void big_epilogue(const GemmP& p, f32x4_t (&acc)[TM][
                     if (p.pre) io8_store<TO>((TO*)p.pre + off, v);
                     if (p.mul) {
 #pragma unroll
-                        for (int e = 0; e < 8; e++) v[e] *= act_bwd(p.act, ex[e]);
+                        for (int e = 0; e < 8; e++) v[e] *= act_bwd<TO>(p.act, ex[e]);
                     } else if (p.act) {
 #pragma unroll
-                        for (int e = 0; e < 8; e++) v[e] = act_fwd(p.act, v[e]);
+                        for (int e = 0; e < 8; e++) v[e] = act_fwd<TO>(p.act, v[e]);
                     }
                     if (p.res) {
 #pragma unroll

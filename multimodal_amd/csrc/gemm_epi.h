@@ -17,13 +17,14 @@ struct GemmP {
     int stagger;                   // large-tile kernel: the two waves of a SIMD run half a K step apart
 };
 
-__device__ __forceinline__ float act_fwd(int act, float v) {
-    if (act == 1) return gelu_erf(v);
+// TO = bf16: the result is rounded to bf16, the short GELU of common.h is exact to that rounding; TO = float: exact erf
+template <typename TO> __device__ __forceinline__ float act_fwd(int act, float v) {
+    if (act == 1) return sizeof(TO) == 2 ? gelu_fast(v) : gelu_erf(v);
     if (act == 2) { const float r = fmaxf(v, 0.f); return r * r; }
     return v;
 }
-__device__ __forceinline__ float act_bwd(int act, float pre) {
-    if (act == 1) return gelu_erf_grad(pre);
+template <typename TO> __device__ __forceinline__ float act_bwd(int act, float pre) {
+    if (act == 1) return sizeof(TO) == 2 ? gelu_fast_grad(pre) : gelu_erf_grad(pre);
     if (act == 2) return 2.f * fmaxf(pre, 0.f);
     return 1.f;
 }
@@ -56,10 +57,10 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmP& p, float (&v)[4], lo
         if (full) VecIO<TO, 4>::load(mul + off, h);
         else { for (int e = 0; e < 4; e++) if (n + e < p.N) h[e] = to_f(mul[off + e]); }
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] *= act_bwd(p.act, h[e]);
+        for (int e = 0; e < 4; e++) v[e] *= act_bwd<TO>(p.act, h[e]);
     } else if (p.act) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = act_fwd(p.act, v[e]);
+        for (int e = 0; e < 4; e++) v[e] = act_fwd<TO>(p.act, v[e]);
     }
     if (p.gamma) {
 #pragma unroll
@@ -116,10 +117,10 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmP& p, float (&v)[8], lo
         if (vec) io8_load<TO>(mul + off, h);
         else { for (int e = 0; e < lim; e++) h[e] = to_f(mul[off + e]); }
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] *= act_bwd(p.act, h[e]);
+        for (int e = 0; e < 8; e++) v[e] *= act_bwd<TO>(p.act, h[e]);
     } else if (p.act) {
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = act_fwd(p.act, v[e]);
+        for (int e = 0; e < 8; e++) v[e] = act_fwd<TO>(p.act, v[e]);
     }
     if (p.gamma) {
 #pragma unroll
