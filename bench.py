@@ -157,10 +157,11 @@ def _event_time(fn, iters=20, warmup=3):
 
 def k2_roofline(device, C=1600, Ln=31):
     """K2: the pointwise-conv MLP of a stage-3 ConvNeXt block (convnext.py:41-45: Linear C->4C, GELU, Linear 4C->C with
-    LayerScale + residual in the epilogues) on the MFMA GEMM `gemm_k`, bf16: SURVEY 8d flops 16*B*L*C^2 per block forward,
+    LayerScale + residual in the epilogues) on libmmhip's MFMA GEMM (these shapes take the large-tile kernel gemm_big_k, which
+    splits K for the skinny 4C -> C product), bf16: SURVEY 8d flops 16*B*L*C^2 per block forward,
     at the config batch (M = B*L = 992 rows: too few tiles to fill 256 CUs) and at a saturating batch."""
     from multimodal_amd import ops
-    out = {"kernel": "gemm_k<bf16,128x128> x2 (pwconv1+GELU, pwconv2+LayerScale+residual)", "bound": "mfma", "unit": "TFLOP/s",
+    out = {"kernel": "gemm_big_k<bf16> x2 (pwconv1+GELU, pwconv2+LayerScale+residual)", "bound": "mfma", "unit": "TFLOP/s",
            "peak": MFMA_BF16_PEAK_TFLOPS, "traffic": None, "shape": {"C": C, "L": Ln, "dtype": "bfloat16"}}
     w1 = (torch.randn(4 * C, C, device=device) * 0.02).to(torch.bfloat16)
     w2 = (torch.randn(C, 4 * C, device=device) * 0.02).to(torch.bfloat16)
