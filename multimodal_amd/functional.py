@@ -282,14 +282,22 @@ class ConvNeXtBlock(torch.autograd.Function):
         global _join_queued
         main, side = enter_side(x.device)
         with torch.cuda.stream(side):
-            dw2 = ops.gemm(dz, a, Cc, 4 * Cc, M, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32,
+            # the two weight gradients go straight into their gradient-bucket slots when dp.GradBuckets marked them fresh (as the
+            # decoder's do, _weight_grad): finish() then has nothing to copy for them
+            s2, s1 = _fresh_slot(w2), _fresh_slot(w1)
+            dw2 = ops.gemm(dz, a, Cc, 4 * Cc, M, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, out=s2,
                            split_k=_split_k(Cc, 4 * Cc, M), ws_tag="gemm_side")
             db1 = ops.colsum(dh, M, 4 * Cc, "side")
-            dw1 = ops.gemm(dh, xn.view(M, Cc), 4 * Cc, Cc, M, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32,
+            dw1 = ops.gemm(dh, xn.view(M, Cc), 4 * Cc, Cc, M, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, out=s1,
                            split_k=_split_k(4 * Cc, Cc, M), ws_tag="gemm_side")
+            if s2 is not None:
+                dw2 = _slot_written(w2, s2)
+            if s1 is not None:
+                dw1 = _slot_written(w1, s1)
         _keepalive.append((dz, dh, a, xn))     # incl. saved activations (freed when this node is released)
         for t in (dw2, db1, dw1):
-            t.record_stream(main)
+            if t is not None:
+                t.record_stream(main)
         _order_accumulation(((w2, dw2), (ctx.b1, db1), (w1, dw1)), main, side)
         if not _join_queued:
             _join_queued = True
@@ -603,6 +611,26 @@ def _linear_res(x2: Tensor, w: Tensor, b: Tensor, res: Tensor) -> Tensor:
     if dt == torch.bfloat16 or _gemm_backend == "own":
         return ops.gemm(x2, cached_operand((w,), dt), x2.shape[0], w.shape[0], w.shape[1], bias=b.detach(), res=res)
     return torch.addmm(b.detach(), x2, w.detach().t()).add_(res)
+
+
+def _fresh_slot(p: Tensor) -> Optional[Tensor]:
+    """The parameter's gradient-bucket slot if a gradient may be WRITTEN there now (dp.GradBuckets.zero() marked it fresh and
+    nothing has been accumulated since), else None."""
+    g = getattr(p, "_mm_view", None)
+    if g is not None and getattr(p, "_mm_fresh", False) and p.grad is None and g.dtype == torch.float32 and g.shape == p.shape:
+        return g
+    return None
+
+
+def _slot_written(p: Tensor, g: Tensor) -> None:
+    """The gradient of p has been produced in its bucket slot g: point .grad at it, tell the bucket; the autograd node returns
+    None for this parameter."""
+    p.grad = g
+    p._mm_fresh = False
+    ready = getattr(p, "_mm_ready", None)
+    if ready is not None:
+        ready(p)
+    return None
 
 
 def _weight_grad(p: Tensor, dy2: Tensor, x2: Tensor) -> Optional[Tensor]:
